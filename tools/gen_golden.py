@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference); the reference never travels to
+the GPU box, the small .npz fixtures do.  Absent third-party imports the reference pulls in
+at module import time are stubbed with empty modules: torchvision (VGG only),
+turtle (a stray import), pysepm, torchaudio (only the two dB one-liners are provided, pinned
+by the reference's own KAT from test/metrics_test.ipynb cell 11).
+
+Usage:  python tools/gen_golden.py [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+
+
+def _stub_modules():
+    def mod(name):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        return m
+    tv = mod("torchvision"); tv.models = mod("torchvision.models")
+    mod("turtle").forward = None
+    mod("pysepm")
+    ta = mod("torchaudio"); taf = mod("torchaudio.functional"); ta.functional = taf
+
+    def amplitude_to_DB(x, multiplier, amin, db_multiplier, top_db=None):
+        return multiplier * torch.log10(torch.clamp(x, min=amin)) - multiplier * db_multiplier
+
+    def DB_to_amplitude(x, ref, power):
+        return ref * torch.pow(torch.pow(10.0, 0.1 * x), power)
+    taf.amplitude_to_DB = amplitude_to_DB
+    taf.DB_to_amplitude = DB_to_amplitude
+
+
+def _np(t):
+    return t.detach().cpu().numpy().copy()      # copy: state_dict tensors alias live parameters
+
+
+def gen_mdct(out):
+    from models.mdct import MDCT4, IMDCT4
+    from util.util import kbdwin
+    d = {}
+    for N in (16, 48, 64, 512, 1024, 2048):
+        d[f"kbdwin_{N}"] = _np(kbdwin(N))
+    # (name, n_fft, hop, win, input shape, center)
+    cases = [
+        ("n16_1d", 16, 8, 16, (72,), True),
+        ("n16_b3", 16, 8, 16, (3, 72), True),
+        ("n16_b3_odd", 16, 8, 16, (3, 77), True),           # quirk: pad from B % hop, T not hop-aligned
+        ("n16_b8_odd", 16, 8, 16, (8, 77), True),           # B % hop == 0 branch
+        ("n16_nocenter", 16, 8, 16, (2, 80), False),
+        ("n64_b2", 64, 32, 64, (2, 480), True),
+        ("n64_hop16", 64, 16, 64, (2, 480), True),          # 75 % overlap
+        ("n64_win48", 64, 24, 48, (2, 480), True),          # win < n_fft (zero-padded frames)
+        ("n1024_b2", 1024, 512, 1024, (2, 7 * 512), True),
+        ("n1024_b2_odd", 1024, 512, 1024, (2, 3700), True),
+        ("n2048_b1", 2048, 1024, 2048, (1, 5 * 1024), True),
+    ]
+    g = torch.Generator().manual_seed(1234)
+    meta = []
+    for name, n_fft, hop, win, shape, center in cases:
+        x = torch.randn(*shape, generator=g) * 0.1
+        x.requires_grad_(True)
+        mdct = MDCT4(n_fft=n_fft, hop_length=hop, win_length=win, window=kbdwin, center=center, device="cpu")
+        S = mdct(x)
+        cot = torch.randn(S.shape, generator=g, dtype=torch.float64)
+        (gx,) = torch.autograd.grad((S * cot).sum(), x)
+        d[f"{name}_x"] = _np(x)
+        d[f"{name}_S"] = _np(S)
+        d[f"{name}_cot"] = _np(cot)
+        d[f"{name}_gx"] = _np(gx)
+        if S.dim() == 3:
+            imdct = IMDCT4(n_fft=n_fft, hop_length=hop, win_length=win, window=kbdwin, center=center, device="cpu")
+            S2 = S.detach().clone().requires_grad_(True)
+            y = imdct(S2)
+            ycot = torch.randn(y.shape, generator=g, dtype=torch.float64)
+            (gS,) = torch.autograd.grad((y * ycot).sum(), S2)
+            d[f"{name}_y"] = _np(y)
+            d[f"{name}_ycot"] = _np(ycot)
+            d[f"{name}_gS"] = _np(gS)
+            imdct_ol = IMDCT4(n_fft=n_fft, hop_length=hop, win_length=win, window=kbdwin, center=center,
+                              out_length=shape[-1], device="cpu")
+            d[f"{name}_y_outlen"] = _np(imdct_ol(S.detach()))
+        meta.append(f"{name},{n_fft},{hop},{win},{int(center)}," + "x".join(map(str, shape)))
+    d["cases"] = np.array(meta)
+    # frame-count quirk table: frames for (B, T) at N=1024 (bit-exact integer target)
+    rows = []
+    mdct = MDCT4(n_fft=1024, hop_length=512, win_length=1024, window=kbdwin, center=True, device="cpu")
+    for B in (1, 2, 3, 256, 512, 513):
+        for T in (130560, 130300, 130816, 1024, 1500):
+            rows.append((B, T, mdct(torch.zeros(B, T)).shape[1]))
+    d["quirk_frames_n1024"] = np.array(rows, dtype=np.int64)
+    # round-trip MSE pins (README.md:115 geometry: 130816 samples, fp32 + fp64 window)
+    x = torch.randn(130816, generator=g)
+    S = mdct(x)
+    imdct = IMDCT4(n_fft=1024, hop_length=512, win_length=1024, window=kbdwin, center=True, device="cpu")
+    y = imdct(S.unsqueeze(0)).squeeze()
+    d["roundtrip_shape"] = np.array(S.shape)
+    d["roundtrip_mse_fp32win"] = np.array(float(((y[: x.numel()] - x) ** 2).mean()))
+    np.savez_compressed(os.path.join(out, "mdct4.npz"), **d)
+    print("mdct4.npz", len(d), "arrays")
+
+
+def _sd(net):
+    return OrderedDict((k, _np(v)) for k, v in net.state_dict().items())
+
+
+def gen_networks(out):
+    import models.networks as RN
+    import contextlib, io
+    d = {}
+    torch.manual_seed(1234)
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    def run_G(tag, net, x):
+        x = x.clone().requires_grad_(True)
+        y = net(x)
+        cot = torch.randn_like(y)
+        grads = torch.autograd.grad((y * cot).sum(), [x] + list(net.parameters()))
+        d[f"{tag}_x"] = _np(x); d[f"{tag}_y"] = _np(y); d[f"{tag}_cot"] = _np(cot); d[f"{tag}_gx"] = _np(grads[0])
+        for (k, v), gr in zip(net.named_parameters(), grads[1:]):
+            d[f"{tag}_p_{k}"] = _np(v); d[f"{tag}_g_{k}"] = _np(gr)
+        d[f"{tag}_keys"] = np.array(list(net.state_dict().keys()))
+
+    with quiet:
+        G = RN.define_G(2, 2, 8, "global", 2, 2, 0, 0, "instance", [])
+    run_G("Gglobal", G, torch.rand(2, 2, 32, 16))
+    with quiet:
+        G4 = RN.define_G(2, 2, 2, "global", 4, 1, 0, 0, "instance", [])
+    run_G("Gglobal_nd4", G4, torch.rand(1, 2, 64, 32))
+    with quiet:
+        L = RN.define_G(2, 2, 4, "local", 2, 2, 1, 1, "instance", [])
+    run_G("Glocal", L, torch.rand(2, 2, 32, 32))
+    with quiet:
+        L2 = RN.define_G(2, 2, 4, "local", 1, 1, 2, 1, "instance", [])
+    run_G("Glocal2", L2, torch.rand(1, 2, 32, 32))
+
+    for tag, gi in (("D", True), ("Dnofeat", False)):
+        with quiet:
+            D = RN.define_D(4, 8, 3, "instance", False, 2, gi, [])
+        x = torch.rand(2, 4, 32, 16).requires_grad_(True)
+        res = D(x)
+        flat = [f for s in res for f in s]
+        cots = [torch.randn_like(f) for f in flat]
+        tot = sum((f * c).sum() for f, c in zip(flat, cots))
+        grads = torch.autograd.grad(tot, [x] + list(D.parameters()))
+        d[f"{tag}_x"] = _np(x); d[f"{tag}_gx"] = _np(grads[0])
+        for i, (f, c) in enumerate(zip(flat, cots)):
+            d[f"{tag}_f{i}"] = _np(f); d[f"{tag}_c{i}"] = _np(c)
+        d[f"{tag}_nfeat"] = np.array([len(s) for s in res])
+        for (k, v), gr in zip(D.named_parameters(), grads[1:]):
+            d[f"{tag}_p_{k}"] = _np(v); d[f"{tag}_g_{k}"] = _np(gr)
+        d[f"{tag}_keys"] = np.array(list(D.state_dict().keys()))
+
+    # GANLoss KAT
+    crit = RN.GANLoss(use_lsgan=True, tensor=torch.FloatTensor)
+    pred = [[torch.rand(2, 1, 5, 3)], [torch.rand(2, 1, 3, 2)]]
+    d["ganloss_p0"] = _np(pred[0][0]); d["ganloss_p1"] = _np(pred[1][0])
+    d["ganloss_real"] = np.array(float(crit(pred, True))); d["ganloss_fake"] = np.array(float(crit(pred, False)))
+
+    # parameter-count + key-list KATs at the real configurations (train_script.sh:38,49-71)
+    counts = {}
+    with quiet:
+        for name, args in {
+            "G_local_ngf48_nd4_nbg3_nle1_nbl2": (2, 2, 48, "local", 4, 3, 1, 2),
+            "G_global_ngf48_nd4_nb9": (2, 2, 48, "global", 4, 9, 0, 0),
+            "G_global_ngf32_nd4_nb9": (2, 2, 32, "global", 4, 9, 0, 0),
+            "G_local_ngf64_default": (2, 2, 64, "local", 4, 9, 1, 3),
+            "G_local_ngf48_nd3_nb9_nle2_nbl3": (2, 2, 48, "local", 3, 9, 2, 3),
+        }.items():
+            net = RN.define_G(*args, "instance", [])
+            counts[name] = sum(p.numel() for p in net.parameters())
+            d[f"keys_{name}"] = np.array(list(net.state_dict().keys()))
+            del net
+        for name, args in {"D_ndf64_nl3_numD2": (4, 64, 3, "instance", False, 2, True),
+                           "D_ndf64_nl3_numD3": (4, 64, 3, "instance", False, 3, True)}.items():
+            net = RN.define_D(*args, [])
+            counts[name] = sum(p.numel() for p in net.parameters())
+            d[f"keys_{name}"] = np.array(list(net.state_dict().keys()))
+    d["count_names"] = np.array(list(counts.keys()))
+    d["count_values"] = np.array(list(counts.values()), dtype=np.int64)
+    np.savez_compressed(os.path.join(out, "networks.npz"), **d)
+    print("networks.npz", len(d), "arrays;", counts)
+
+
+def gen_model(out):
+    """Pix2PixHDModel on CPU with the reference's own MDCT4 swapped in for MDCT2 (README.md:133 invites it)."""
+    import contextlib, io
+    from types import SimpleNamespace
+    from models.pix2pixHD_model import Pix2PixHDModel
+    from models.mdct import MDCT4, IMDCT4
+    d = {}
+    opt = SimpleNamespace(
+        gpu_ids=[], isTrain=True, checkpoints_dir="/tmp/p2phd_golden", name="g", resize_or_crop="none",
+        instance_feat=False, label_feat=False, load_features=False, label_nc=0, input_nc=2, output_nc=2,
+        hr_sampling_rate=48000, lr_sampling_rate=8000, n_fft=64, hop_length=32, win_length=64, center=True,
+        no_instance=True, feat_num=3, ngf=8, netG="global", n_downsample_global=2, n_blocks_global=2,
+        n_local_enhancers=1, n_blocks_local=1, norm="instance", no_lsgan=False, ndf=8, n_layers_D=3, num_D=2,
+        no_ganFeat_loss=False, use_hifigan_D=False, use_time_D=False, verbose=False, continue_train=False,
+        load_pretrain="", which_epoch="latest", pool_size=0, lr=0.0002, beta1=0.5, no_vgg_loss=True,
+        use_match_loss=False, niter_fix_global=0, explicit_encoding=True, alpha=0.6, min_value=1e-7, mask=True,
+        mask_mode="mode2", phase_encoding_mode=None, lambda_feat=10.0, lambda_mat=10.0, lambda_time=0.4,
+        abs_spectro=True, fp16=False, nef=16, n_downsample_E=4)
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = Pix2PixHDModel()
+        model.initialize(opt)
+    # MDCT4 returns float64 (complex128 twiddles, mdct.py:483-484) which the fp32 conv stack rejects;
+    # the cast to fp32 right after the transform is the one documented deviation.
+    _m4 = MDCT4(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=model.window, device="cpu")
+    class _Cast32(torch.nn.Module):
+        def forward(self, a):
+            return _m4(a).float()
+    model._mdct = _Cast32()
+    model._imdct = IMDCT4(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=model.window, device="cpu")
+    frames = 16
+    T = (frames - 1) * opt.hop_length
+    B = 2
+    g = torch.Generator().manual_seed(77)
+    hr = 0.1 * torch.randn(B, T, generator=g)
+    lr = 0.1 * torch.randn(B, T, generator=g)
+    d["hr"] = _np(hr); d["lr"] = _np(lr)
+    d["window"] = _np(model.window)
+    # hr: no randomness
+    hs, hpha, hnorm = model.to_spectro(hr, mask=False)
+    d["hr_spectro"] = _np(hs); d["hr_pha"] = _np(hpha)
+    d["hr_max"] = _np(hnorm["max"]); d["hr_min"] = _np(hnorm["min"])
+    # lr: the reference draws torch.randn inside; replay the same draw to record the noise it used
+    bins = opt.n_fft // 2
+    mask_size = int(bins * (1 - 1 / (48000 / 8000)))
+    torch.manual_seed(4321)
+    ls, lpha, lnorm = model.to_spectro(lr, mask=True)
+    torch.manual_seed(4321)
+    noise = torch.randn(B, 2, mask_size, frames)
+    d["mask_noise"] = _np(noise)
+    d["lr_spectro"] = _np(ls); d["lr_pha"] = _np(lpha)
+    d["lr_max"] = _np(lnorm["max"]); d["lr_min"] = _np(lnorm["min"])
+    # to_audio on the hr spectrogram (fp32 dtype path: reference multiplies fp64 MDCT output; cast here)
+    aud = model.to_audio(hs.float(), {k: v.float() for k, v in hnorm.items() if k in ("max", "min")})
+    d["hr_audio_rt"] = _np(aud)
+    # full forward + the two backward passes (train.py:155-184)
+    for k, v in model.netG.state_dict().items():
+        d[f"G_p_{k}"] = _np(v)
+    for k, v in model.netD.state_dict().items():
+        d[f"D_p_{k}"] = _np(v)
+    # the mask noise is an input of the parity tests: hand the recorded tensor to the reference's
+    # torch.randn call (pix2pixHD_model.py:202) instead of relying on generator state
+    _randn = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    try:
+        losses, sr = model.forward(lr, None, hr, None, infer=True)
+    finally:
+        torch.randn = _randn
+    names = model.loss_names
+    d["loss_names"] = np.array(names)
+    d["loss_values"] = np.array([float(l) for l in losses], dtype=np.float64)
+    d["sr"] = _np(sr)
+    ld = dict(zip(names, losses))
+    loss_D = (ld["D_fake"] + ld["D_real"]) * 0.5
+    loss_G = ld["G_GAN"] + ld.get("G_GAN_Feat", 0)
+    model.optimizer_G.zero_grad(); loss_G.backward(retain_graph=True)
+    for k, v in model.netG.named_parameters():
+        d[f"G_g_{k}"] = _np(v.grad)
+    model.optimizer_G.step()
+    model.optimizer_D.zero_grad(); loss_D.backward()
+    for k, v in model.netD.named_parameters():
+        d[f"D_g_{k}"] = _np(v.grad)
+    model.optimizer_D.step()
+    for k, v in model.netG.state_dict().items():
+        d[f"G_p1_{k}"] = _np(v)
+    for k, v in model.netD.state_dict().items():
+        d[f"D_p1_{k}"] = _np(v)
+    d["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(out, "model_step.npz"), **d)
+    print("model_step.npz", len(d), "arrays; losses", dict(zip(names, d["loss_values"])))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    _stub_modules()
+    sys.path.insert(0, REF)
+    torch.set_num_threads(4)
+    todo = a.only.split(",") if a.only else ["mdct", "networks", "model"]
+    if "mdct" in todo:
+        gen_mdct(a.out)
+    if "networks" in todo:
+        gen_networks(a.out)
+    if "model" in todo:
+        gen_model(a.out)
+
+
+if __name__ == "__main__":
+    main()
