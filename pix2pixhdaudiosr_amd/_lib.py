@@ -1,0 +1,77 @@
+"""ctypes binding of libp2phd_hip.so (the C ABI declared in include/p2phd.h).
+
+There is deliberately no CPU fallback: if the shared library is missing or a call fails the
+product path raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C pix2pixhdaudiosr_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libp2phd_hip.so")
+
+F32, BF16 = 0, 1
+_i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/p2phd.h (tests check this)
+SIGNATURES = {
+    "p2phd_last_error": (C.c_char_p, []),
+    "p2phd_abi_version": (_i32, []),
+    "p2phd_device_info": (_i32, [C.c_char_p, _i32]),
+    "p2phd_mdct4_tables_floats": (C.c_size_t, [_i32]),
+    "p2phd_mdct4_tables_fill": (_i32, [_i32, _vp]),
+    "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    "p2phd_mdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "p2phd_imdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class P2PHDError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `make -C pix2pixhdaudiosr_amd/csrc` or `__graft_entry__.build()`); "
+                "this package has no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().p2phd_last_error().decode("utf-8", "replace")
+        raise P2PHDError(f"{what or 'p2phd'} failed (code {rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def require_gpu_tensor(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise P2PHDError(f"{name}: expected a tensor on the GPU (this build has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise P2PHDError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise P2PHDError(f"{name}: expected a contiguous tensor")
+    return t

@@ -1,0 +1,34 @@
+// Error channel, ABI version and device query of libp2phd_hip.so.
+#include "common.h"
+#include <cstring>
+
+namespace p2phd {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace p2phd
+
+extern "C" const char* p2phd_last_error(void) { return p2phd::g_err; }
+extern "C" int p2phd_abi_version(void) { return 1; }
+
+extern "C" int p2phd_device_info(char* name, int cap) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    p2phd::set_error("no HIP device");
+    return P2PHD_ELAUNCH;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    p2phd::set_error("hipGetDeviceProperties failed");
+    return P2PHD_ELAUNCH;
+  }
+  if (name && cap > 0) {
+    strncpy(name, prop.gcnArchName, cap - 1);
+    name[cap - 1] = 0;
+  }
+  return prop.multiProcessorCount;
+}
