@@ -74,6 +74,108 @@ int p2phd_imdct4_fwd(const float* spec, int64_t B, int64_t n_frames, int n_fft, 
                      const float* window, const float* tables, int64_t crop_start, int64_t out_len,
                      float scale, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Activation tensors of the conv stack are NHWC ("channels last": [N, H, W, Cp]) with the channel
+ * pitch Cp = p2phd_channel_pitch(C) = C rounded up to 8; pad channels hold zeros.  dtype is
+ * P2PHD_F32 (exact-f32 MFMA, parity runs) or P2PHD_BF16 (bf16 MFMA, fp32 accumulate).
+ * ---------------------------------------------------------------------------------------- */
+int p2phd_channel_pitch(int channels);
+
+#define P2PHD_ACT_NONE  0
+#define P2PHD_ACT_LRELU 1   /* LeakyReLU(0.2), models/networks.py:342,350,358 */
+#define P2PHD_ACT_TANH  2   /* models/networks.py:160,207 */
+#define P2PHD_ACT_RELU  3
+
+/* One Conv2d / ConvTranspose2d layer of models/networks.py.
+ *   transposed = 0: nn.Conv2d(C, K, (R,S), stride, padding=pad); with pad_mode = 1 the layer is
+ *                   nn.ReflectionPad2d(pad) followed by nn.Conv2d(..., padding=0) (networks.py:190,223-231);
+ *   transposed = 1: nn.ConvTranspose2d(C, K, (R,S), stride, padding=pad, output_padding=opad) (:205).
+ * Master weights keep the PyTorch layouts ([K,C,R,S], resp. [C,K,R,S]) in f32. */
+typedef struct p2phd_conv_desc {
+  int32_t N, C, H, W;
+  int32_t K, R, S;
+  int32_t stride, pad, pad_mode, transposed, opad;
+  int32_t dtype;
+} p2phd_conv_desc;
+
+int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
+
+/* Packed (K-contiguous, tap-major, zero-padded) weights for the forward (which = 0) or the input-gradient
+ * (which = 1) launches; repack after every optimizer step. */
+size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which);
+int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w, void* packed, void* stream);
+
+/* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], zeroed by the caller) the per-(n,channel)
+ * sum and sum of squares of conv(x)+bias are accumulated into it (what InstanceNorm2d needs, networks.py:22). */
+int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_fwd, const float* bias, int act,
+                   void* y, float* stats, void* stream);
+
+/* dx = conv^T(dy) (+ addend, same layout as dx).  Replaces autograd of F.conv2d / F.conv_transpose2d and, for
+ * pad_mode = 1, of ReflectionPad2d as well (needs p2phd_conv_dgrad_workspace_bytes of scratch). */
+size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c);
+int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const void* packed_dgrad, const void* addend, void* dx,
+                     void* workspace, void* stream);
+
+/* dw (master layout, f32, overwritten) and db (f32 [K], overwritten, may be NULL) from x and dy. */
+size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c);
+int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, void* workspace,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * HBM-bound companions (csrc/norm.hip).  NHWC tensors, channel pitch = p2phd_channel_pitch(C).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out = act((y - mean) * rstd) + residual: InstanceNorm2d(affine=False, eps) (networks.py:22) + ReLU /
+ * LeakyReLU(0.2) / none, + the ResnetBlock skip (networks.py:252) or the LocalEnhancer sum (:180) when
+ * residual != NULL.  stats = the float [N][Cp][2] (sum, sum of squares) p2phd_conv_fwd accumulated. */
+int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
+                           int N, int64_t HW, int C, float eps, int act, void* stream);
+/* dy from g = dL/d(out) through act and InstanceNorm; bstats: float [N][Cp][2] scratch (zeroed inside). */
+int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                           int N, int64_t HW, int C, float eps, int act, void* stream);
+/* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */
+int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream);
+
+/* nn.AvgPool2d(3, stride=2, padding=[1,1], count_include_pad=False) (networks.py:165,308). */
+int p2phd_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+int p2phd_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream);
+
+/* Module-boundary layout converters: f32 NCHW [N,C,HW] <-> channels [ch_off, ch_off+C) of NHWC [N,HW,Cp]. */
+int p2phd_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream);
+int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Losses and optimiser (csrc/loss.hip).
+ * kind 0: mean((a - target)^2)  -- GANLoss with use_lsgan (networks.py:68-110)
+ * kind 1: mean(|a - b|)         -- criterionFeat = L1Loss (pix2pixHD_model.py:99,391-398)
+ * a, b: [P][Cp] activations with C valid channels; *out += coeff * mean; the backward reads the upstream
+ * gradient from device memory (*grad_out) so no host synchronisation is needed.
+ * ---------------------------------------------------------------------------------------- */
+int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C, float coeff,
+                   float* out, void* stream);
+int p2phd_loss_bwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C, float coeff,
+                   const float* grad_out, void* da, void* stream);
+/* torch.optim.Adam (no amsgrad / weight decay) over one flat f32 buffer; grads are scaled by grad_scale first
+ * (1/world_size after a summing all-reduce).  step counts from 1. */
+int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Spectrogram codec (csrc/spectro.hip): Pix2PixHDModel.to_spectro / denormalize / to_audio with
+ * explicit_encoding (pix2pixHD_model.py:142-249).
+ * encode: spec [B,F,M] f32 (MDCT4 output) -> log_spectro [B,2,M,F] in [0,1], pha [B,1,M,F],
+ *   norm8 = (min, max, mean, std, noise_min, noise_max, -, -) on the device.  The top mask_rows bins are
+ *   replaced by min-max scaled `noise` [B,2,mask_rows,F] (mask_mode 'mode2'), or zeros if noise == NULL.
+ *   partials: scratch of p2phd_spectro_partials_floats(B,F,M) floats.
+ * decode: log_spectro [B,2,M,F] + (min,max) -> spec [B,F,M] ready for IMDCT4.
+ * ---------------------------------------------------------------------------------------- */
+int64_t p2phd_spectro_partials_floats(int64_t B, int64_t F, int64_t M);
+int p2phd_spectro_encode(const float* spec, int64_t B, int64_t F, int64_t M, float alpha, float min_value,
+                         int mask_rows, const float* noise, float* log_spectro, float* pha, float* norm8,
+                         float* partials, void* stream);
+int p2phd_spectro_decode(const float* log_spectro, const float* norm_min_max, int64_t B, int64_t F, int64_t M,
+                         float alpha, float min_value, float* spec, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

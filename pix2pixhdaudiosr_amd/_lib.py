@@ -25,7 +25,35 @@ SIGNATURES = {
     "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "p2phd_mdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "p2phd_imdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "p2phd_channel_pitch": (_i32, [_i32]),
+    "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
+    "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "p2phd_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "p2phd_conv_dgrad_workspace_bytes": (C.c_size_t, [_vp]),
+    "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_wgrad_workspace_bytes": (C.c_size_t, [_vp]),
+    "p2phd_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_instnorm_act_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
+    "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
+    "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "p2phd_avgpool3s2_fwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "p2phd_avgpool3s2_bwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "p2phd_nchw_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "p2phd_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "p2phd_loss_fwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp]),
+    "p2phd_loss_bwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
+    "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
+    "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_spectro_decode": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _vp]),
 }
+
+
+class ConvDesc(C.Structure):
+    """struct p2phd_conv_desc (include/p2phd.h)."""
+    _fields_ = [(n, C.c_int32) for n in ("N", "C", "H", "W", "K", "R", "S", "stride", "pad", "pad_mode",
+                                         "transposed", "opad", "dtype")]
 
 _lib = None
 

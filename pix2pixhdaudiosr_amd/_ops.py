@@ -1,0 +1,314 @@
+"""Host-side glue between torch tensors and the conv-stack entry points of libp2phd_hip.so.
+
+Internal activation format ("physical" tensors): contiguous NHWC ``[N, H, W, Cp]`` in the compute dtype
+(torch.bfloat16 or torch.float32), Cp = channels rounded up to 8 with zero pad channels.  Everything here
+is plumbing: allocation through torch's caching allocator, pointers and the current stream handed to the
+C ABI, and ``torch.autograd.Function`` wrappers whose backward calls the HIP backward kernels.
+"""
+import ctypes as C
+import contextlib
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check, lib, ptr, stream_ptr
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+IN_EPS = 1e-5                      # nn.InstanceNorm2d default, models/networks.py:22
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+# bumped whenever master weights change behind torch's back (fused Adam, load_state_dict...)
+_WEIGHT_EPOCH = [0]
+# when set, conv blocks built in this scope skip their weight gradient (result-identical elision of the D
+# weight gradients that train.py:176 zeroes before they are ever used)
+_SKIP_WGRAD = [False]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
+
+@contextlib.contextmanager
+def no_weight_grad():
+    prev = _SKIP_WGRAD[0]
+    _SKIP_WGRAD[0] = True
+    try:
+        yield
+    finally:
+        _SKIP_WGRAD[0] = prev
+
+
+def cpitch(c):
+    return (c + 7) & ~7
+
+
+def dt_code(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise _lib.P2PHDError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+
+
+_WS = {}
+
+
+def workspace(nbytes, device):
+    """Grow-only scratch buffer per device; kernels on one stream run in order, so consecutive ops share it."""
+    key = str(device)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
+def phys(t, what="activation"):
+    """Validate a physical NHWC tensor."""
+    if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dim() == 4 and t.is_contiguous() and t.shape[-1] % 8 == 0
+            and t.dtype in _DT):
+        raise _lib.P2PHDError(f"{what}: expected a contiguous GPU NHWC tensor with channel pitch % 8 == 0 in f32/bf16, "
+                              f"got {type(t).__name__} {getattr(t, 'shape', None)} {getattr(t, 'dtype', None)}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------
+# layout
+# ------------------------------------------------------------------------------------------
+
+def to_physical(x_nchw, dtype, out=None, ch_off=0):
+    """f32 NCHW -> NHWC physical (channels [ch_off, ch_off+C)); `out` lets several tensors be concatenated."""
+    x = x_nchw.contiguous().float()
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = torch.zeros((N, H, W, cpitch(ch_off + Cc)), dtype=dtype, device=x.device)
+    check(lib().p2phd_nchw_to_nhwc(dt_code(out.dtype), ptr(x), ptr(out), N, Cc, H * W, out.shape[-1], ch_off, stream_ptr()),
+          "nchw_to_nhwc")
+    return out
+
+
+def from_physical(x_phys, channels, ch_off=0):
+    N, H, W, Cp = x_phys.shape
+    out = torch.empty((N, channels, H, W), dtype=torch.float32, device=x_phys.device)
+    check(lib().p2phd_nhwc_to_nchw(dt_code(x_phys.dtype), ptr(x_phys), ptr(out), N, channels, H * W, Cp, ch_off, stream_ptr()),
+          "nhwc_to_nchw")
+    return out
+
+
+class ToPhysical(torch.autograd.Function):
+    """NCHW f32 (one or two tensors concatenated along channels) -> physical NHWC."""
+
+    @staticmethod
+    def forward(ctx, dtype, *xs):
+        ctx.chans = [int(x.shape[1]) for x in xs]
+        total = sum(ctx.chans)
+        N, _, H, W = xs[0].shape
+        out = torch.zeros((N, H, W, cpitch(total)), dtype=dtype, device=xs[0].device)
+        off = 0
+        for x in xs:
+            to_physical(x, dtype, out=out, ch_off=off)
+            off += int(x.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        grads, off = [], 0
+        for i, c in enumerate(ctx.chans):
+            grads.append(from_physical(g, c, off) if ctx.needs_input_grad[1 + i] else None)
+            off += c
+        return (None, *grads)
+
+
+class FromPhysical(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_phys, channels):
+        ctx.meta = (x_phys.dtype, x_phys.shape[-1])
+        return from_physical(x_phys, channels)
+
+    @staticmethod
+    def backward(ctx, g):
+        dtype, Cp = ctx.meta
+        N, Cc, H, W = g.shape
+        out = torch.zeros((N, H, W, Cp), dtype=dtype, device=g.device)
+        to_physical(g, dtype, out=out)
+        return out, None
+
+
+# ------------------------------------------------------------------------------------------
+# convolution block: [ReflectionPad] -> Conv2d/ConvTranspose2d -> [InstanceNorm] -> [act] -> [+ residual]
+# ------------------------------------------------------------------------------------------
+
+class ConvSpec:
+    """Static description of one reference layer; builds the C descriptor for a given input size."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, pad_mode=0, transposed=False, opad=0, norm=False, act=ACT_NONE):
+        self.cin, self.cout, self.k = cin, cout, k
+        self.stride, self.pad, self.pad_mode = stride, pad, pad_mode
+        self.transposed, self.opad = transposed, opad
+        self.norm, self.act = norm, act
+        self._packed = {}
+
+    def desc(self, N, H, W, dtype):
+        return ConvDesc(N, self.cin, H, W, self.cout, self.k, self.k, self.stride, self.pad, self.pad_mode,
+                        int(self.transposed), self.opad, dt_code(dtype))
+
+    def out_size(self, d):
+        ho, wo = C.c_int32(), C.c_int32()
+        check(lib().p2phd_conv_out_size(C.byref(d), C.byref(ho), C.byref(wo)), "conv_out_size")
+        return ho.value, wo.value
+
+    def packed(self, weight, which, d):
+        """Packed weights for forward (0) / input gradient (1); re-packed when the master copy changed.
+        The dgrad pack of a stride-1 reflect conv depends on H, W only through the descriptor checks."""
+        key = (which, d.dtype)
+        stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
+        self._packed[key] = (stamp, buf)
+        return buf
+
+
+class ConvBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, spec):
+        x = phys(x, "conv input")
+        N, H, W, Cp_in = x.shape
+        if Cp_in != cpitch(spec.cin):
+            raise _lib.P2PHDError(f"conv: input has channel pitch {Cp_in}, layer expects {cpitch(spec.cin)} ({spec.cin} channels)")
+        d = spec.desc(N, H, W, x.dtype)
+        Ho, Wo = spec.out_size(d)
+        L = lib()
+        Cp_out = cpitch(spec.cout)
+        wp = spec.packed(weight, 0, d)
+        b = None if bias is None else bias.detach().float().contiguous()
+        y = torch.empty((N, Ho, Wo, Cp_out), dtype=x.dtype, device=x.device)
+        stats = torch.zeros((N, Cp_out, 2), dtype=torch.float32, device=x.device) if spec.norm else None
+        fused_act = ACT_NONE if spec.norm else spec.act
+        check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), stream_ptr()), "conv_fwd")
+        if spec.norm:
+            res = None if residual is None else phys(residual, "residual")
+            out = torch.empty_like(y)
+            check(L.p2phd_instnorm_act_fwd(d.dtype, ptr(y), ptr(stats), ptr(res), ptr(out), N, Ho * Wo, spec.cout, IN_EPS,
+                                           spec.act, stream_ptr()), "instnorm_act_fwd")
+        else:
+            if residual is not None:
+                raise _lib.P2PHDError("residual add is only fused behind InstanceNorm")
+            out = y
+        ctx.spec, ctx.d = spec, d
+        ctx.skip_wgrad = _SKIP_WGRAD[0]
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.x, ctx.y, ctx.stats, ctx.weight = x, y, stats, weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        spec, d = ctx.spec, ctx.d
+        L = lib()
+        x, y, stats, weight = ctx.x, ctx.y, ctx.stats, ctx.weight
+        g = g.contiguous()
+        if g.dtype != y.dtype:
+            g = g.to(y.dtype)
+        N, Ho, Wo, Cp_out = y.shape
+        if spec.norm:
+            dy = torch.empty_like(y)
+            bstats = torch.empty((N, Cp_out, 2), dtype=torch.float32, device=y.device)
+            check(L.p2phd_instnorm_act_bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), N, Ho * Wo, spec.cout,
+                                           IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd")
+        elif spec.act != ACT_NONE:
+            dy = torch.empty_like(y)
+            check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
+        else:
+            dy = g
+        gx = gw = gb = None
+        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if need_w and not ctx.skip_wgrad:
+            gw = torch.empty(weight.shape, dtype=torch.float32, device=y.device)
+            gb = torch.empty((spec.cout,), dtype=torch.float32, device=y.device) if ctx.has_bias else None
+            ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device)
+            check(L.p2phd_conv_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+        if ctx.needs_input_grad[0]:
+            wp = spec.packed(weight, 1, d)
+            gx = torch.empty_like(x)
+            wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))
+            ws = workspace(wsb, y.device) if wsb else None
+            check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), None, ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
+        gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        return gx, gw, gb, gres, None
+
+
+def conv_block(x, weight, bias, spec, residual=None):
+    return ConvBlockFn.apply(x, weight, bias, residual, spec)
+
+
+# ------------------------------------------------------------------------------------------
+# AvgPool2d(3, 2, 1, count_include_pad=False)
+# ------------------------------------------------------------------------------------------
+
+class AvgPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, channels):
+        x = phys(x, "avgpool input")
+        N, H, W, Cp = x.shape
+        Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+        y = torch.empty((N, Ho, Wo, Cp), dtype=x.dtype, device=x.device)
+        check(lib().p2phd_avgpool3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), N, H, W, channels, stream_ptr()), "avgpool_fwd")
+        ctx.meta = (N, H, W, Cp, channels)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, Cp, channels = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty((N, H, W, Cp), dtype=g.dtype, device=g.device)
+        check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
+        return dx, None
+
+
+def avgpool(x, channels):
+    return AvgPoolFn.apply(x, channels)
+
+
+# ------------------------------------------------------------------------------------------
+# losses
+# ------------------------------------------------------------------------------------------
+
+class LossFn(torch.autograd.Function):
+    """kind 0: mean((a-target)^2) ; kind 1: mean(|a-b|) * coeff.  Returns a 0-dim f32 device tensor."""
+
+    @staticmethod
+    def forward(ctx, a, b, kind, target, coeff, channels):
+        a = phys(a, "loss input")
+        P = a.numel() // a.shape[-1]
+        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(a), ptr(b), float(target), P, channels, float(coeff),
+                                   ptr(out), stream_ptr()), "loss_fwd")
+        ctx.meta = (kind, float(target), float(coeff), channels, P)
+        ctx.a, ctx.b = a, b
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        kind, target, coeff, channels, P = ctx.meta
+        a, b = ctx.a, ctx.b
+        da = torch.empty_like(a)
+        g = g.contiguous().float()
+        check(lib().p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(a), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
+                                   stream_ptr()), "loss_bwd")
+        return da, None, None, None, None, None
+
+
+def mse_const_loss(a_phys, channels, target):
+    return LossFn.apply(a_phys, None, 0, target, 1.0, channels)
+
+
+def l1_loss(a_phys, b_phys, channels, coeff=1.0):
+    return LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels)

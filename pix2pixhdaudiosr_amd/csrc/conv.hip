@@ -1,0 +1,669 @@
+// Convolution family of the pix2pixHD generator / discriminator for gfx950, as implicit GEMMs on MFMA.
+//
+// Reference layers covered (models/networks.py): Conv2d 7x7 s1 behind ReflectionPad2d(3) (:190,207),
+// Conv2d 3x3 s2 p1 (:194), Conv2d 3x3 s1 behind ReflectionPad2d(1) (:231,246), ConvTranspose2d 3x3 s2 p1
+// op1 (:205), Conv2d 4x4 s2/s1 p2 (:342-361), each with forward, input gradient and weight gradient.
+//
+// One primitive serves all of them: a GATHER CONVOLUTION over NHWC activations
+//     out[n, ho*om+oo, wo*om'+oo', k] = sum_{tap t} sum_c in[n, ho*s + dh(t), wo*s + dw(t), c] * Wp[k][t][c]
+// with zero or reflect boundary handling folded into the gather index.  Forward convs, the input gradient of
+// stride-1 convs and of ConvTranspose2d are single launches; ConvTranspose2d forward and the input gradient
+// of stride-2 convs are run as stride^2 sub-pixel classes (each a stride-1 gather with its own tap subset and
+// an interleaved output lattice), so no zero-stuffed tensor and no col2im scatter ever exists.
+//
+// GEMM view: M = output pixels (tiles never straddle samples), N = output channels, K = taps x channels.
+// 128 x BN x (128 bytes of K) tiles; 4 wavefronts; A (gathered pixels) and B (packed weights, K-contiguous
+// rows) are staged global -> registers -> LDS in 16-byte pieces (coalesced along the channel axis = the
+// frequency-major NHWC inner dimension), double-buffered with the next tile's loads issued before the MFMAs of
+// the current one; LDS rows are 128 B with a 16-byte-chunk XOR swizzle ((row>>1)&7) so the ds_read_b128
+// fragment reads of v_mfma_f32_32x32x16_bf16 are bank-conflict free.  fp32 mode (parity runs) uses the exact
+// v_mfma_f32_32x32x2_f32 on the same tiles.  The epilogue adds bias, accumulates the per-(n,channel) sum and
+// sum of squares InstanceNorm needs (wave reduction + one float atomic per wave and channel), applies an
+// optional activation, stages the tile in LDS and writes whole 16-byte pieces of NHWC rows.
+//
+// The weight gradient is a second kernel: M = out channels, N = taps x in channels, reduction over pixels.
+// Both operands then have the reduction index as the slow LDS dimension; bf16 fragments are fetched with the
+// gfx950 transposing read ds_read_b64_tr_b16, so no transposed copy of the activations is made.
+#include "common.h"
+#include "convplan.h"
+
+namespace {
+
+using p2phd::GDesc;
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__device__ uint4 g_zero_page[4];   // zero-initialised: source of every out-of-image / padding piece
+
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPP = 4; };    // elements per 16-byte piece
+template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case P2PHD_ACT_LRELU: return v > 0.f ? v : 0.2f * v;
+    case P2PHD_ACT_TANH: return tanhf(v);
+    case P2PHD_ACT_RELU: return v > 0.f ? v : 0.f;
+    default: return v;
+  }
+}
+
+constexpr int kBM = 128;
+constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
+
+// ------------------------------------------------------------------------------------------------------
+// gather convolution
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int WGM, int WGN, int MR, int NR>
+__global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
+                                                    const float* __restrict__ bias, const T* __restrict__ addend,
+                                                    T* __restrict__ out, float* __restrict__ stats) {
+  constexpr int EPP = Elem<T>::EPP;
+  constexpr int BK = 8 * EPP;
+  constexpr int BM = kBM;
+  static_assert(WGM * WGN == 4 && WGM * MR * 32 == BM && WGN * NR * 32 == BN, "tile config");
+  constexpr int STAGE = (BM + BN) * kRowBytes;
+  constexpr int NB = BN / 32;      // B pieces per thread per step
+
+  extern __shared__ float4 smem_raw[];
+  char* smem = reinterpret_cast<char*>(smem_raw);
+  const int T_taps = d.nth * d.ntw;
+  int* tab = reinterpret_cast<int*>(smem);
+  char* stages = smem + ((T_taps * BM * 4 + 15) & ~15);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int npix = d.Hg * d.Wg;
+  const int mtiles = (npix + BM - 1) / BM;
+  const int n = blockIdx.x / mtiles;
+  const int p_base = (blockIdx.x - n * mtiles) * BM;
+  const int n0 = blockIdx.y * BN;
+
+  // gather table: input pixel index (or -1) per (tap, tile row)
+  for (int e = tid; e < T_taps * BM; e += 256) {
+    const int t = e / BM, r = e - t * BM;
+    const int p = p_base + r;
+    int off = -1;
+    if (p < npix) {
+      const int ho = p / d.Wg, wo = p - ho * d.Wg;
+      const int ta = t / d.ntw, tb = t - ta * d.ntw;
+      int hi = ho * d.sh + d.dh0 + ta * d.dh_step;
+      int wi = wo * d.sw + d.dw0 + tb * d.dw_step;
+      if (d.pad_mode == 1) { hi = reflect_idx(hi, d.Hin); wi = reflect_idx(wi, d.Win); }
+      if (hi >= 0 && hi < d.Hin && wi >= 0 && wi < d.Win) off = (n * d.Hin + hi) * d.Win + wi;
+    }
+    tab[e] = off;
+  }
+  __syncthreads();
+
+  const int chunk = tid & 7, rbase = tid >> 3;
+  const int swz = (chunk ^ ((rbase >> 1) & 7)) << 4;       // rows handled by this thread are rbase + 32 i
+  const int Cp = d.Cp_in;
+  int a_t = (chunk * EPP) / Cp, a_c = (chunk * EPP) % Cp;
+  const T* bptr = wp + (size_t)(n0 + rbase) * d.KK + chunk * EPP;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+  uint4 ra[4], rb[NB];
+
+  auto issue_loads = [&](int step) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T* src = zero;
+      if (a_t < T_taps) {
+        const int off = tab[a_t * BM + rbase + 32 * i];
+        if (off >= 0) src = in + (size_t)off * Cp + a_c;
+      }
+      ra[i] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(32 * i) * d.KK + (size_t)step * BK);
+    a_c += BK;
+    while (a_c >= Cp) { a_c -= Cp; ++a_t; }
+  };
+  auto write_lds = [&](int stage) {
+    char* A = stages + stage * STAGE;
+    char* B = A + BM * kRowBytes;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(A + (rbase + 32 * i) * kRowBytes + swz) = ra[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(B + (rbase + 32 * i) * kRowBytes + swz) = rb[i];
+  };
+
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  auto compute = [&](int stage) {
+    const char* A = stages + stage * STAGE;
+    const char* B = A + BM * kRowBytes;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int jj = 2 * ks + lh;
+      uint4 af[MR], bfr[NR];
+#pragma unroll
+      for (int i = 0; i < MR; ++i) {
+        const int row = wm * (MR * 32) + i * 32 + lr;
+        af[i] = *reinterpret_cast<const uint4*>(A + row * kRowBytes + ((jj ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < NR; ++j) {
+        const int row = wn * (NR * 32) + j * 32 + lr;
+        bfr[j] = *reinterpret_cast<const uint4*>(B + row * kRowBytes + ((jj ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[i]),
+                                                                *reinterpret_cast<bf16x8*>(&bfr[j]), acc[i][j], 0, 0, 0);
+          } else {
+            // exact f32 MFMA; any k permutation is fine as long as A and B share it
+            const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[i]);
+            const f32x4 b4 = *reinterpret_cast<f32x4*>(&bfr[j]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
+  };
+
+  const int nsteps = d.KK / BK;
+  issue_loads(0);
+  write_lds(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) issue_loads(s + 1);
+    compute(s & 1);
+    if (s + 1 < nsteps) write_lds((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
+  constexpr int CROW = BN * (int)sizeof(T) + 16;            // padded C-tile row
+  char* ct = stages;
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int col = wn * (NR * 32) + j * 32 + lr;
+    const int k = n0 + col;
+    const float bv = (bias != nullptr && k < d.Kout) ? bias[k] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MR; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float v = acc[i][j][e] + bv;
+        if (p_base + row < npix) { s1 += v; s2 += v * v; }
+        v = apply_act(v, d.act);
+        *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
+      }
+    }
+    if (stats != nullptr) {
+      s1 += __shfl_xor(s1, 32);
+      s2 += __shfl_xor(s2, 32);
+      if (lh == 0 && k < d.Kout) {
+        atomicAdd(&stats[2 * ((size_t)n * d.Cp_out + k)], s1);
+        atomicAdd(&stats[2 * ((size_t)n * d.Cp_out + k) + 1], s2);
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / EPP;                              // 16-byte pieces per C-tile row
+  for (int q = tid; q < BM * CPR; q += 256) {
+    const int row = q / CPR, pc = q - row * CPR;
+    const int p = p_base + row;
+    const int k = n0 + pc * EPP;
+    if (p >= npix || k >= d.Cp_out) continue;
+    const int ho = p / d.Wg, wo = p - ho * d.Wg;
+    const size_t opix = ((size_t)n * d.Hout + (ho * d.oh_mul + d.oh_off)) * d.Wout + (wo * d.ow_mul + d.ow_off);
+    uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
+    if (addend != nullptr) {
+      const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * d.Cp_out + k);
+      T* vv = reinterpret_cast<T*>(&v);
+      const T* aa = reinterpret_cast<const T*>(&a);
+#pragma unroll
+      for (int e = 0; e < EPP; ++e) vv[e] = from_f<T>(to_f(vv[e]) + to_f(aa[e]));
+    }
+    *reinterpret_cast<uint4*>(out + opix * d.Cp_out + k) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradient:  dWp[m][t*Cg + c] (+)= sum_p rows[p][m] * gather[pix(p,t)][c]
+//   rows   : [N*Hg*Wg][Cp_r]   the tensor on the pixel grid (dy for Conv2d, x for ConvTranspose2d)
+//   gather : [N,Hin,Win,Cp_in] the tensor reached through the taps
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
+                                                    float* __restrict__ dwp, int Cp_r, int steps_per_split, int use_atomic) {
+  constexpr int EPP = Elem<T>::EPP;
+  constexpr int BKP = sizeof(T) == 2 ? 64 : 32;             // pixels per K-step
+  constexpr int TM = 128, TN = 128;
+  constexpr int ROWB = TM * (int)sizeof(T) + (sizeof(T) == 2 ? 64 : 0);   // padded LDS row (conflict-free tr reads)
+  constexpr int TILE = BKP * ROWB;
+  constexpr int CPR = TM / EPP;                             // pieces per row
+  constexpr int PPT = BKP * CPR / 256;                      // pieces per thread per tile
+  constexpr int RSTEP = 256 / CPR;                          // row distance between a thread's pieces
+
+  extern __shared__ float4 smem_raw[];
+  char* smem = reinterpret_cast<char*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int j0 = blockIdx.x * TN;                           // first kk column
+  const int m0 = blockIdx.y * TM;                           // first output row
+  const int npix = d.Hg * d.Wg;
+  const long P = (long)d.N * npix;
+  const int total_steps = (int)((P + BKP - 1) / BKP);
+  const int s_begin = blockIdx.z * steps_per_split;
+  int s_end = s_begin + steps_per_split;
+  if (s_end > total_steps) s_end = total_steps;
+  if (s_begin >= s_end) return;
+
+  const int chunk = tid % CPR, rb = tid / CPR;
+  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+  // rows-operand: column fixed per thread
+  const int mcol = m0 + chunk * EPP;
+  const bool mvalid = mcol < Cp_r;
+  // gather-operand: (tap, channel) fixed per thread
+  const int kk = j0 + chunk * EPP;
+  const int T_taps = d.nth * d.ntw;
+  const int g_t = kk / d.Cp_in, g_c = kk - g_t * d.Cp_in;
+  const bool gvalid = g_t < T_taps;
+  const int ta = g_t / d.ntw, tb = g_t - ta * d.ntw;
+  const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
+
+  // per-piece pixel coordinates, advanced incrementally (no division in the loop)
+  int pn[PPT], ph[PPT], pw[PPT];
+  long pp[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const long p = (long)s_begin * BKP + rb + RSTEP * i;
+    pp[i] = p;
+    const long nn = p / npix;
+    const int rem = (int)(p - nn * npix);
+    pn[i] = (int)nn; ph[i] = rem / d.Wg; pw[i] = rem - ph[i] * d.Wg;
+  }
+
+  uint4 ra[PPT], rg[PPT];
+  auto issue_loads = [&]() {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const T* s1 = zero;
+      const T* s2 = zero;
+      if (pp[i] < P) {
+        if (mvalid) s1 = rows + (size_t)pp[i] * Cp_r + mcol;
+        if (gvalid) {
+          int hi = ph[i] * d.sh + dh, wi = pw[i] * d.sw + dw;
+          if (d.pad_mode == 1) { hi = reflect_idx(hi, d.Hin); wi = reflect_idx(wi, d.Win); }
+          if (hi >= 0 && hi < d.Hin && wi >= 0 && wi < d.Win)
+            s2 = gat + ((size_t)(pn[i] * d.Hin + hi) * d.Win + wi) * d.Cp_in + g_c;
+        }
+      }
+      ra[i] = *reinterpret_cast<const uint4*>(s1);
+      rg[i] = *reinterpret_cast<const uint4*>(s2);
+      pp[i] += BKP;
+      pw[i] += BKP;
+      while (pw[i] >= d.Wg) { pw[i] -= d.Wg; ++ph[i]; }
+      while (ph[i] >= d.Hg) { ph[i] -= d.Hg; ++pn[i]; }
+    }
+  };
+  auto write_lds = [&](int stage) {
+    char* A = smem + stage * 2 * TILE;
+    char* G = A + TILE;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int row = rb + RSTEP * i;
+      *reinterpret_cast<uint4*>(A + row * ROWB + chunk * 16) = ra[i];
+      *reinterpret_cast<uint4*>(G + row * ROWB + chunk * 16) = rg[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto compute = [&](int stage) {
+    const char* A = smem + stage * 2 * TILE;
+    const char* G = A + TILE;
+    if constexpr (sizeof(T) == 2) {
+      // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i
+      const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3, h = g >> 1;
+      const int colo = (16 * (g & 1) + 4 * pq) * 2;
+#pragma unroll
+      for (int sub = 0; sub < BKP / 16; ++sub) {
+        const int prow = 16 * sub + 8 * h + q;
+        bf16x8 af[2], gf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const char* pa = A + prow * ROWB + (wm * 64 + i * 32) * 2 + colo;
+          const char* pg = G + prow * ROWB + (wn * 64 + i * 32) * 2 + colo;
+          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
+          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
+          const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pg));
+          const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pg + 4 * ROWB));
+          s16x4* ad = reinterpret_cast<s16x4*>(&af[i]);
+          s16x4* gd = reinterpret_cast<s16x4*>(&gf[i]);
+          ad[0] = a0; ad[1] = a1; gd[0] = g0; gd[1] = g1;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll 4
+      for (int s2 = 0; s2 < BKP / 2; ++s2) {
+        const int prow = 2 * s2 + lh;
+        float af[2], gf[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          af[i] = *reinterpret_cast<const float*>(A + prow * ROWB + (wm * 64 + i * 32 + lr) * 4);
+          gf[i] = *reinterpret_cast<const float*>(G + prow * ROWB + (wn * 64 + i * 32 + lr) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], gf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  issue_loads();
+  write_lds(0);
+  __syncthreads();
+  int st = 0;
+  for (int s = s_begin; s < s_end; ++s) {
+    if (s + 1 < s_end) issue_loads();
+    compute(st);
+    if (s + 1 < s_end) write_lds(st ^ 1);
+    __syncthreads();
+    st ^= 1;
+  }
+
+  const int lr = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = j0 + wn * 64 + j * 32 + lr;
+      if (col >= d.KK) continue;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        float* dst = dwp + (size_t)row * d.KK + col;
+        if (use_atomic) atomicAdd(dst, acc[i][j][e]);
+        else *dst = acc[i][j][e];
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// weight packing: master f32 tensor (generic strides) -> Wp[rows_pad][KK] of T, zero padded
+// and the inverse for gradients (packed f32 -> master layout, overwrite)
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_kernel(GDesc d, const float* __restrict__ w, T* __restrict__ wp, int rows, int rows_pad, int inner,
+                            long s_row, long s_inner, int S) {
+  const long total = (long)rows_pad * d.KK;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / d.KK);
+    const int kk = (int)(e - (long)row * d.KK);
+    const int t = kk / d.Cp_in, c = kk - t * d.Cp_in;
+    float v = 0.f;
+    if (row < rows && t < d.nth * d.ntw && c < inner) {
+      const int ta = t / d.ntw, tb = t - ta * d.ntw;
+      const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
+      v = w[row * s_row + c * s_inner + r * S + s];
+    }
+    wp[e] = from_f<T>(v);
+  }
+}
+
+__global__ void unpack_grad_kernel(GDesc d, const float* __restrict__ dwp, float* __restrict__ dw, int rows, int inner,
+                                   long s_row, long s_inner, int S) {
+  const int T_taps = d.nth * d.ntw;
+  const long total = (long)rows * T_taps * inner;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(e % inner);
+    const long r2 = e / inner;
+    const int t = (int)(r2 % T_taps);
+    const int row = (int)(r2 / T_taps);
+    const int ta = t / d.ntw, tb = t - ta * d.ntw;
+    const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
+    dw[row * s_row + c * s_inner + r * S + s] = dwp[(size_t)row * d.KK + t * d.Cp_in + c];
+  }
+}
+
+// reflect-pad adjoint: dx[n,i,j,:] = sum over padded positions that mirror onto (i,j) of dxp (+ addend)
+template <typename T>
+__global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restrict__ addend, T* __restrict__ dx,
+                                    int N, int H, int W, int Cp, int P) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long total = (long)N * H * W * cpr;
+  const int Hp = H + 2 * P, Wp = W + 2 * P;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int pc = (int)(e % cpr);
+    long r = e / cpr;
+    const int j = (int)(r % W); r /= W;
+    const int i = (int)(r % H);
+    const int n = (int)(r / H);
+    int hs[2], ws[2], nh = 1, nw = 1;
+    hs[0] = i + P; ws[0] = j + P;
+    if (i >= 1 && i <= P) hs[nh++] = P - i;
+    else if (i >= H - 1 - P && i <= H - 2) hs[nh++] = 2 * (H - 1) - i + P;
+    if (j >= 1 && j <= P) ws[nw++] = P - j;
+    else if (j >= W - 1 - P && j <= W - 2) ws[nw++] = 2 * (W - 1) - j + P;
+    float acc[EPP];
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+    for (int a = 0; a < nh; ++a)
+      for (int b = 0; b < nw; ++b) {
+        const uint4 v = *reinterpret_cast<const uint4*>(dxp + (((size_t)n * Hp + hs[a]) * Wp + ws[b]) * Cp + pc * EPP);
+        const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+      }
+    const size_t o = (((size_t)n * H + i) * W + j) * Cp + pc * EPP;
+    if (addend != nullptr) {
+      const uint4 v = *reinterpret_cast<const uint4*>(addend + o);
+      const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+    }
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) oo[k] = from_f<T>(acc[k]);
+    *reinterpret_cast<uint4*>(dx + o) = ov;
+  }
+}
+
+// column sums of a [P][Cp] matrix (bias gradient); db must be zeroed beforehand
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ x, long P, int Cp, int K, float* __restrict__ db) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const int pc = threadIdx.x % cpr;            // blockDim.x is a multiple of cpr (host guarantees)
+  const int rl = threadIdx.x / cpr;
+  const int rows_per_block = blockDim.x / cpr;
+  float acc[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+  for (long p = (long)blockIdx.x * rows_per_block + rl; p < P; p += (long)gridDim.x * rows_per_block) {
+    const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)p * Cp + pc * EPP);
+    const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) {
+    const int c = pc * EPP + k;
+    if (c < K) atomicAdd(&db[c], acc[k]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int BN, int WGM, int WGN, int MR, int NR>
+int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
+                     float* stats, hipStream_t st) {
+  constexpr int STAGE = (kBM + BN) * kRowBytes;
+  constexpr int CT = kBM * (BN * (int)sizeof(T) + 16);
+  const int tab = (d.nth * d.ntw * kBM * 4 + 15) & ~15;
+  const size_t lds = tab + (size_t)(2 * STAGE > CT ? 2 * STAGE : CT);
+  auto kern = gconv_kernel<T, BN, WGM, WGN, MR, NR>;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int mtiles = (d.Hg * d.Wg + kBM - 1) / kBM;
+  const int ntiles = (d.Cp_out + BN - 1) / BN;
+  dim3 grid((unsigned)(mtiles * d.N), (unsigned)ntiles);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
+  return p2phd::check_launch("gconv");
+}
+
+template <typename T>
+int launch_gconv_t(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
+                   float* stats, hipStream_t st) {
+  // pick the N tile that wastes the fewest MFMA columns
+  const int k = d.Cp_out;
+  auto waste = [&](int bn) { return ((k + bn - 1) / bn) * bn - k; };
+  int bn = 128;
+  if (waste(64) < waste(bn)) bn = 64;
+  if (waste(32) < waste(bn)) bn = 32;
+  if (bn == 128) return launch_gconv_cfg<T, 128, 2, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
+  if (bn == 64) return launch_gconv_cfg<T, 64, 2, 2, 2, 1>(d, in, wp, bias, addend, out, stats, st);
+  return launch_gconv_cfg<T, 32, 4, 1, 1, 1>(d, in, wp, bias, addend, out, stats, st);
+}
+
+}  // namespace
+
+namespace p2phd {
+
+int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
+                 void* out, float* stats, hipStream_t st) {
+  if (d.N == 0 || d.Hg * d.Wg == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(d.Cp_in % 8 == 0 && d.Cp_out % 8 == 0, "gconv: channel pitch must be a multiple of 8");
+  P2PHD_REQUIRE((long)d.N * d.Hin * d.Win < (1l << 31) && (long)d.N * d.Hout * d.Wout < (1l << 31), "gconv: too many pixels");
+  if (dtype == P2PHD_BF16) return launch_gconv_t<bf16_t>(d, in, wp, bias, addend, out, stats, st);
+  if (dtype == P2PHD_F32) return launch_gconv_t<float>(d, in, wp, bias, addend, out, stats, st);
+  set_error("gconv: unsupported dtype %d", dtype);
+  return P2PHD_EUNSUPPORTED;
+}
+
+int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows_pad, const void* gat, float* dwp,
+                 hipStream_t st) {
+  // dwp: [M_rows_pad][KK] f32, M_rows_pad a multiple of 128
+  const long P = (long)d.N * d.Hg * d.Wg;
+  const int bkp = dtype == P2PHD_BF16 ? 64 : 32;
+  const int total_steps = (int)((P + bkp - 1) / bkp);
+  const int tiles = (M_rows_pad / 128) * ((d.KK + 127) / 128);
+  if (total_steps == 0) {
+    (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
+    return P2PHD_OK;
+  }
+  // split the pixel reduction until the grid covers the chip ~3x, keeping >= 8 steps per split
+  int splits = 1;
+  while (tiles * splits < 768 && total_steps / (splits * 2) >= 8) splits *= 2;
+  const int sps = (total_steps + splits - 1) / splits;
+  splits = (total_steps + sps - 1) / sps;
+  const int use_atomic = splits > 1;
+  if (use_atomic) (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
+  dim3 grid((unsigned)((d.KK + 127) / 128), (unsigned)(M_rows_pad / 128), (unsigned)splits);
+  if (dtype == P2PHD_BF16) {
+    constexpr int lds = 2 * 2 * 64 * (128 * 2 + 64);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, d, (const bf16_t*)rows, (const bf16_t*)gat, dwp, Cp_r, sps, use_atomic);
+  } else if (dtype == P2PHD_F32) {
+    constexpr int lds = 2 * 2 * 32 * (128 * 4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, d, (const float*)rows, (const float*)gat, dwp, Cp_r, sps, use_atomic);
+  } else {
+    set_error("wgrad: unsupported dtype %d", dtype);
+    return P2PHD_EUNSUPPORTED;
+  }
+  return check_launch("wgrad");
+}
+
+int launch_pack(const GDesc& d, int dtype, const float* w, void* wp, int rows, int rows_pad, int inner, long s_row,
+                long s_inner, int S, hipStream_t st) {
+  const long total = (long)rows_pad * d.KK;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, d, w, (bf16_t*)wp, rows, rows_pad, inner, s_row, s_inner, S);
+  else
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, d, w, (float*)wp, rows, rows_pad, inner, s_row, s_inner, S);
+  return check_launch("pack_weights");
+}
+
+int launch_unpack_grad(const GDesc& d, const float* dwp, float* dw, int rows, int inner, long s_row, long s_inner, int S,
+                       hipStream_t st) {
+  const long total = (long)rows * d.nth * d.ntw * inner;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, dwp, dw, rows, inner, s_row, s_inner, S);
+  return check_launch("unpack_grad");
+}
+
+int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
+                        hipStream_t st) {
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const long total = (long)N * H * W * (Cp / epp);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(reflect_fold_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dxp, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, Cp, P);
+  else
+    hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dxp, (const float*)addend, (float*)dx, N, H, W, Cp, P);
+  return check_launch("reflect_fold");
+}
+
+int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st) {
+  (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)K, st);
+  if (P == 0) return P2PHD_OK;
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const int cpr = Cp / epp;
+  P2PHD_REQUIRE(cpr <= 1024, "colsum: too many channels");
+  int threads = (256 / cpr) * cpr;
+  if (threads == 0) threads = cpr;
+  const int rpb = threads / cpr;
+  const int blocks = (int)std::min<long>((P + rpb * 8 - 1) / (rpb * 8), 2048);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, st, (const bf16_t*)x, P, Cp, K, db);
+  else
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(threads), 0, st, (const float*)x, P, Cp, K, db);
+  return check_launch("colsum");
+}
+
+}  // namespace p2phd

@@ -1,0 +1,34 @@
+// Internal descriptor of one gather-convolution launch and the launchers implemented in conv.hip.
+#pragma once
+#include "common.h"
+#include <algorithm>
+
+namespace p2phd {
+
+struct GDesc {
+  int N, Hin, Win, Cp_in;          // gathered tensor (NHWC, channel pitch Cp_in)
+  int Hg, Wg;                      // GEMM-row grid per sample
+  int sh, sw, pad_mode;            // gather stride; 0 = zeros outside, 1 = reflect
+  int Hout, Wout, Cp_out;          // written tensor
+  int oh_mul, oh_off, ow_mul, ow_off;   // output lattice: (ho*oh_mul+oh_off, wo*ow_mul+ow_off)
+  int Kout, KK, act;               // valid output channels, padded GEMM-K (row length of packed weights)
+  int nth, ntw, dh0, dh_step, dw0, dw_step;   // tap (a,b): offset (dh0+a*dh_step, dw0+b*dw_step)
+  int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
+};
+
+inline int cpitch(int c) { return (c + 7) & ~7; }
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
+                 void* out, float* stats, hipStream_t st);
+int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows_pad, const void* gat, float* dwp,
+                 hipStream_t st);
+int launch_pack(const GDesc& d, int dtype, const float* w, void* wp, int rows, int rows_pad, int inner, long s_row,
+                long s_inner, int S, hipStream_t st);
+int launch_unpack_grad(const GDesc& d, const float* dwp, float* dw, int rows, int inner, long s_row, long s_inner, int S,
+                       hipStream_t st);
+int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
+                        hipStream_t st);
+int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st);
+
+}  // namespace p2phd

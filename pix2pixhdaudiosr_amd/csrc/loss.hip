@@ -1,0 +1,141 @@
+// Scalar losses of the GAN step and the fused Adam update.
+//   LSGAN criterion   models/networks.py:68-110  : mean((pred - target)^2), target 1.0 / 0.0
+//   feature matching  models/pix2pixHD_model.py:391-398 : mean(|a - b|), b detached
+//   Adam              torch.optim.Adam(lr, betas=(beta1, 0.999)) as built at pix2pixHD_model.py:131,140
+// Losses reduce on the device into a float accumulator (no host sync); their backward kernels read the upstream
+// gradient from device memory too, so the whole step can be enqueued without the host waiting on a value.
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) for (unsigned i = 0; i < (blockDim.x + 63) / 64; ++i) t += red[i];
+  __syncthreads();
+  return t;   // valid in thread 0
+}
+
+// kind 0: (a - target)^2 ; kind 1: |a - b|.  a,b are [P][Cp] with C valid channels.  out += coeff * sum / (P*C)
+template <typename T>
+__global__ __launch_bounds__(256) void loss_fwd_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, float target,
+                                                       long P, int C, int Cp, float coeff, float* __restrict__ out) {
+  __shared__ float red[4];
+  const long total = P * C;
+  float acc = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long p = e / C;
+    const int c = (int)(e - p * C);
+    const float av = to_f(a[(size_t)p * Cp + c]);
+    if (kind == 0) { const float d = av - target; acc += d * d; }
+    else acc += fabsf(av - to_f(b[(size_t)p * Cp + c]));
+  }
+  const float t = block_sum(acc, red);
+  if (threadIdx.x == 0) atomicAdd(out, t * coeff / (float)total);
+}
+
+// da[p][c] = (*gup) * coeff * f'(a) / (P*C), pad channels zero
+template <typename T>
+__global__ __launch_bounds__(256) void loss_bwd_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, float target,
+                                                       long P, int C, int Cp, float coeff, const float* __restrict__ gup,
+                                                       T* __restrict__ da) {
+  const long total = P * Cp;
+  const float s = (*gup) * coeff / (float)(P * C);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % Cp);
+    float g = 0.f;
+    if (c < C) {
+      const float av = to_f(a[e]);
+      if (kind == 0) g = 2.f * (av - target) * s;
+      else { const float d = av - to_f(b[e]); g = d > 0.f ? s : (d < 0.f ? -s : 0.f); }
+    }
+    da[e] = from_f<T>(g);
+  }
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt, float gscale) {
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 256 * 4) {
+    if (e + 4 <= n) {
+      float4 pp = *reinterpret_cast<float4*>(p + e);
+      const float4 gg = *reinterpret_cast<const float4*>(g + e);
+      float4 mm = *reinterpret_cast<float4*>(m + e);
+      float4 vv = *reinterpret_cast<float4*>(v + e);
+      float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gr = ga[k] * gscale;
+        ma[k] = b1 * ma[k] + (1.f - b1) * gr;
+        va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+        pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<float4*>(p + e) = pp;
+      *reinterpret_cast<float4*>(m + e) = mm;
+      *reinterpret_cast<float4*>(v + e) = vv;
+    } else {
+      for (long i = e; i < n; ++i) {
+        const float gr = g[i] * gscale;
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+      }
+    }
+  }
+}
+
+inline int grid_for(long work, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((work + 255) / 256, cap)); }
+
+}  // namespace
+
+extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C,
+                              float coeff, float* out, void* stream) {
+  P2PHD_REQUIRE(kind == 0 || kind == 1, "loss: kind must be 0 (mse vs constant) or 1 (l1)");
+  P2PHD_REQUIRE(a && out && (kind == 0 || b) && C >= 1, "loss_fwd: bad arguments");
+  if (P == 0) return P2PHD_OK;
+  const int Cp = (C + 7) & ~7;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * C, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out);
+  else if (dtype == P2PHD_F32)
+    hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(grid_for(P * C, 1024)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, out);
+  else { p2phd::set_error("loss_fwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
+  return p2phd::check_launch("loss_fwd");
+}
+
+extern "C" int p2phd_loss_bwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C,
+                              float coeff, const float* grad_out, void* da, void* stream) {
+  P2PHD_REQUIRE(kind == 0 || kind == 1, "loss: kind must be 0 (mse vs constant) or 1 (l1)");
+  P2PHD_REQUIRE(a && da && grad_out && (kind == 0 || b) && C >= 1, "loss_bwd: bad arguments");
+  if (P == 0) return P2PHD_OK;
+  const int Cp = (C + 7) & ~7;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(grid_for(P * Cp)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, grad_out, (bf16_t*)da);
+  else if (dtype == P2PHD_F32)
+    hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(grid_for(P * Cp)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, grad_out, (float*)da);
+  else { p2phd::set_error("loss_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
+  return p2phd::check_launch("loss_bwd");
+}
+
+extern "C" int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                               float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream) {
+  P2PHD_REQUIRE(step >= 1 && n >= 0, "adam: step counts from 1");
+  if (n == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam: null pointer");
+  P2PHD_REQUIRE(((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) % 16 == 0, "adam: buffers must be 16-byte aligned");
+  const double bc1 = 1.0 - std::pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - std::pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                     exp_avg_sq, (long)n, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), grad_scale);
+  return p2phd::check_launch("adam_step");
+}

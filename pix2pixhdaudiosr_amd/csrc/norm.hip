@@ -1,0 +1,433 @@
+// HBM-bound companions of the conv kernels: InstanceNorm2d(affine=False) + activation (+ residual) forward
+// and backward, activation backward, AvgPool2d(3, 2, 1, count_include_pad=False) forward/backward and the
+// NCHW-f32 <-> NHWC layout converters at the module boundary.  All move 16-byte pieces along the channel
+// (innermost NHWC) axis so every wave instruction touches whole 1 KiB / 512 B runs.
+//
+// Reference semantics: models/networks.py:22 (InstanceNorm2d, eps 1e-5, biased variance, no affine, no running
+// stats), :188,233 (ReLU), :342-358 (LeakyReLU 0.2), :165,308 (AvgPool2d), :252 (residual add).
+#include "common.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPP = 4; };
+template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+  if (act == P2PHD_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == P2PHD_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+__device__ __forceinline__ float act_slope(float v, int act) {   // derivative at pre-activation v
+  if (act == P2PHD_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+  if (act == P2PHD_ACT_LRELU) return v > 0.f ? 1.f : 0.2f;
+  return 1.f;
+}
+
+constexpr int kMaxCp = 2048;   // channels staged per block (mean / rstd tables)
+
+// ---- forward: out = act((y - mean) * rstd) + residual --------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stats,
+                                                         const T* __restrict__ residual, T* __restrict__ out, long HW,
+                                                         int C, int Cp, float eps, int act) {
+  constexpr int EPP = Elem<T>::EPP;
+  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp];
+  const int n = blockIdx.y;
+  const float inv = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    float m = 0.f, r = 0.f;
+    if (c < C) {
+      const float s1 = stats[2 * ((size_t)n * Cp + c)], s2 = stats[2 * ((size_t)n * Cp + c) + 1];
+      m = s1 * inv;
+      const float var = fmaxf(s2 * inv - m * m, 0.f);
+      r = rsqrtf(var + eps);
+    }
+    s_mean[c] = m; s_rstd[c] = r;
+  }
+  __syncthreads();
+  const int cpr = Cp / EPP;
+  const long total = HW * cpr;
+  const size_t base = (size_t)n * HW * Cp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int pc = (int)(e % cpr);
+    const size_t o = base + (size_t)e * EPP;
+    const uint4 v = *reinterpret_cast<const uint4*>(y + o);
+    const T* vv = reinterpret_cast<const T*>(&v);
+    uint4 rv = make_uint4(0, 0, 0, 0);
+    if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + o);
+    const T* rr = reinterpret_cast<const T*>(&rv);
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = pc * EPP + k;
+      float f = (to_f(vv[k]) - s_mean[c]) * s_rstd[c];
+      f = act_fwd(f, act);
+      if (residual != nullptr) f += to_f(rr[k]);
+      oo[k] = from_f<T>(c < C ? f : 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + o) = ov;
+  }
+}
+
+// ---- backward pass 1: per (n,c) sums of g' and g' * yhat, g' = g * act'(yhat) ----------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                                const float* __restrict__ stats, float* __restrict__ bstats,
+                                                                long HW, int C, int Cp, float eps, int act, int cpg) {
+  constexpr int EPP = Elem<T>::EPP;
+  __shared__ float red[256 * 8 * 2];
+  const int n = blockIdx.z;
+  const int cpr = Cp / EPP;
+  const int pl = threadIdx.x % cpg, rl = threadIdx.x / cpg, R = 256 / cpg;
+  const int pc = blockIdx.y * cpg + pl;
+  const bool valid = pc < cpr && rl < R;
+  float mean[EPP], rstd[EPP], a1[EPP], a2[EPP];
+  const float inv = 1.f / (float)HW;
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) {
+    a1[k] = a2[k] = 0.f; mean[k] = 0.f; rstd[k] = 0.f;
+    const int c = pc * EPP + k;
+    if (valid && c < C) {
+      const float s1 = stats[2 * ((size_t)n * Cp + c)], s2 = stats[2 * ((size_t)n * Cp + c) + 1];
+      mean[k] = s1 * inv;
+      rstd[k] = rsqrtf(fmaxf(s2 * inv - mean[k] * mean[k], 0.f) + eps);
+    }
+  }
+  if (valid) {
+    const size_t base = (size_t)n * HW * Cp + (size_t)pc * EPP;
+    for (long p = (long)blockIdx.x * R + rl; p < HW; p += (long)gridDim.x * R) {
+      const uint4 gv = *reinterpret_cast<const uint4*>(g + base + (size_t)p * Cp);
+      const uint4 yv = *reinterpret_cast<const uint4*>(y + base + (size_t)p * Cp);
+      const T* gg = reinterpret_cast<const T*>(&gv);
+      const T* yy = reinterpret_cast<const T*>(&yv);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        const float yh = (to_f(yy[k]) - mean[k]) * rstd[k];
+        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        a1[k] += gp; a2[k] += gp * yh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) {
+    red[(threadIdx.x * 8 + k) * 2] = a1[k];
+    red[(threadIdx.x * 8 + k) * 2 + 1] = a2[k];
+  }
+  __syncthreads();
+  if (valid && rl == 0) {
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = pc * EPP + k;
+      if (c >= C) continue;
+      float t1 = 0.f, t2 = 0.f;
+      for (int r = 0; r < R; ++r) {
+        t1 += red[((r * cpg + pl) * 8 + k) * 2];
+        t2 += red[((r * cpg + pl) * 8 + k) * 2 + 1];
+      }
+      atomicAdd(&bstats[2 * ((size_t)n * Cp + c)], t1);
+      atomicAdd(&bstats[2 * ((size_t)n * Cp + c) + 1], t2);
+    }
+  }
+}
+
+// ---- backward pass 2: dy = rstd * (g' - mean(g') - yhat * mean(g' yhat)) ---------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                               const float* __restrict__ stats, const float* __restrict__ bstats,
+                                                               T* __restrict__ dy, long HW, int C, int Cp, float eps, int act) {
+  constexpr int EPP = Elem<T>::EPP;
+  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp], s_m1[kMaxCp], s_m2[kMaxCp];
+  const int n = blockIdx.y;
+  const float inv = 1.f / (float)HW;
+  for (int c = threadIdx.x; c < Cp; c += 256) {
+    float m = 0.f, r = 0.f, m1 = 0.f, m2 = 0.f;
+    if (c < C) {
+      const size_t i = 2 * ((size_t)n * Cp + c);
+      m = stats[i] * inv;
+      r = rsqrtf(fmaxf(stats[i + 1] * inv - m * m, 0.f) + eps);
+      m1 = bstats[i] * inv; m2 = bstats[i + 1] * inv;
+    }
+    s_mean[c] = m; s_rstd[c] = r; s_m1[c] = m1; s_m2[c] = m2;
+  }
+  __syncthreads();
+  const int cpr = Cp / EPP;
+  const long total = HW * cpr;
+  const size_t base = (size_t)n * HW * Cp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int pc = (int)(e % cpr);
+    const size_t o = base + (size_t)e * EPP;
+    const uint4 gv = *reinterpret_cast<const uint4*>(g + o);
+    const uint4 yv = *reinterpret_cast<const uint4*>(y + o);
+    const T* gg = reinterpret_cast<const T*>(&gv);
+    const T* yy = reinterpret_cast<const T*>(&yv);
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = pc * EPP + k;
+      const float yh = (to_f(yy[k]) - s_mean[c]) * s_rstd[c];
+      const float gp = to_f(gg[k]) * act_slope(yh, act);
+      oo[k] = from_f<T>(c < C ? s_rstd[c] * (gp - s_m1[c] - yh * s_m2[c]) : 0.f);
+    }
+    *reinterpret_cast<uint4*>(dy + o) = ov;
+  }
+}
+
+// ---- activation backward from the saved OUTPUT (conv layers whose activation is fused, no norm) ----
+template <typename T>
+__global__ void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a, T* __restrict__ dx, long n_pieces, int act) {
+  constexpr int EPP = Elem<T>::EPP;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < n_pieces; e += (long)gridDim.x * blockDim.x) {
+    const uint4 gv = *reinterpret_cast<const uint4*>(g + e * EPP);
+    const uint4 av = *reinterpret_cast<const uint4*>(a + e * EPP);
+    const T* gg = reinterpret_cast<const T*>(&gv);
+    const T* aa = reinterpret_cast<const T*>(&av);
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const float o = to_f(aa[k]);
+      float s = 1.f;
+      if (act == P2PHD_ACT_TANH) s = 1.f - o * o;
+      else if (act == P2PHD_ACT_LRELU) s = o > 0.f ? 1.f : 0.2f;
+      else if (act == P2PHD_ACT_RELU) s = o > 0.f ? 1.f : 0.f;
+      oo[k] = from_f<T>(to_f(gg[k]) * s);
+    }
+    *reinterpret_cast<uint4*>(dx + e * EPP) = ov;
+  }
+}
+
+// ---- AvgPool2d(3, stride 2, pad 1, count_include_pad=False) -------------------------------------------
+template <typename T>
+__global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int Ho, int Wo, int Cp) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long total = (long)N * Ho * Wo * cpr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int pc = (int)(e % cpr);
+    long r = e / cpr;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho);
+    const int n = (int)(r / Ho);
+    float acc[EPP];
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+    int cnt = 0;
+    for (int a = 0; a < 3; ++a) {
+      const int hi = 2 * ho - 1 + a;
+      if (hi < 0 || hi >= H) continue;
+      for (int b = 0; b < 3; ++b) {
+        const int wi = 2 * wo - 1 + b;
+        if (wi < 0 || wi >= W) continue;
+        ++cnt;
+        const uint4 v = *reinterpret_cast<const uint4*>(x + (((size_t)n * H + hi) * W + wi) * Cp + pc * EPP);
+        const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+      }
+    }
+    const float inv = 1.f / (float)cnt;
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) oo[k] = from_f<T>(acc[k] * inv);
+    *reinterpret_cast<uint4*>(y + (size_t)e * EPP) = ov;
+  }
+}
+
+__device__ __forceinline__ int pool_count(int o, int n) {   // valid taps of output index o along a dim of size n
+  int c = 0;
+  for (int a = 0; a < 3; ++a) { const int i = 2 * o - 1 + a; c += (i >= 0 && i < n); }
+  return c;
+}
+
+template <typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int Ho, int Wo, int Cp) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long total = (long)N * H * W * cpr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int pc = (int)(e % cpr);
+    long r = e / cpr;
+    const int j = (int)(r % W); r /= W;
+    const int i = (int)(r % H);
+    const int n = (int)(r / H);
+    float acc[EPP];
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+    // outputs ho whose window [2*ho-1, 2*ho+1] contains i
+    for (int ho = i / 2; ho <= (i + 1) / 2; ++ho) {
+      if (ho < 0 || ho >= Ho || 2 * ho - 1 > i || 2 * ho + 1 < i) continue;
+      const int ch = pool_count(ho, H);
+      for (int wo = j / 2; wo <= (j + 1) / 2; ++wo) {
+        if (wo < 0 || wo >= Wo || 2 * wo - 1 > j || 2 * wo + 1 < j) continue;
+        const float inv = 1.f / (float)(ch * pool_count(wo, W));
+        const uint4 v = *reinterpret_cast<const uint4*>(dy + (((size_t)n * Ho + ho) * Wo + wo) * Cp + pc * EPP);
+        const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]) * inv;
+      }
+    }
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) oo[k] = from_f<T>(acc[k]);
+    *reinterpret_cast<uint4*>(dx + (size_t)e * EPP) = ov;
+  }
+}
+
+// ---- layout converters ---------------------------------------------------------------------------------
+// src f32 [N,C,HW] -> channels [ch_off, ch_off+C) of dst [N,HW,Cp]; other channels of dst are left untouched
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, long HW, int Cp, int ch_off) {
+  const long total = (long)N * C * HW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const long r = e / HW;
+    const int c = (int)(r % C);
+    const long n = r / C;
+    dst[((size_t)n * HW + p) * Cp + ch_off + c] = from_f<T>(src[e]);
+  }
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, long HW, int Cp, int ch_off) {
+  const long total = (long)N * C * HW;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const long r = e / HW;
+    const int c = (int)(r % C);
+    const long n = r / C;
+    dst[e] = to_f(src[((size_t)n * HW + p) * Cp + ch_off + c]);
+  }
+}
+
+inline int grid_for(long work, int cap = 8192) { return (int)std::max<long>(1, std::min<long>((work + 255) / 256, cap)); }
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, name)                 \
+  if ((dtype) == P2PHD_BF16) { CALL_BF16; }                          \
+  else if ((dtype) == P2PHD_F32) { CALL_F32; }                       \
+  else { p2phd::set_error(name ": unsupported dtype %d", (dtype)); return P2PHD_EUNSUPPORTED; }
+
+}  // namespace
+
+extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
+                                      int N, int64_t HW, int C, float eps, int act, void* stream) {
+  const int Cp = (C + 7) & ~7;
+  P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
+  if (N == 0 || HW == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(y && stats && out, "instnorm_act_fwd: null pointer");
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  dim3 grid(grid_for(HW * (Cp / epp), 2048), N);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, stats, (const bf16_t*)residual, (bf16_t*)out, (long)HW, C, Cp, eps, act),
+             hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)y, stats, (const float*)residual, (float*)out, (long)HW, C, Cp, eps, act),
+             "instnorm_act_fwd");
+  return p2phd::check_launch("instnorm_act_fwd");
+}
+
+extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                                      int N, int64_t HW, int C, float eps, int act, void* stream) {
+  const int Cp = (C + 7) & ~7;
+  P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
+  if (N == 0 || HW == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(g && y && stats && bstats && dy, "instnorm_act_bwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const int cpr = Cp / epp;
+  int cpg = 1;
+  while (cpg * 2 <= cpr && cpg * 2 <= 64) cpg *= 2;            // power of two so 256 % cpg == 0
+  const int R = 256 / cpg;
+  const int ygroups = (cpr + cpg - 1) / cpg;
+  const int xblocks = (int)std::max<long>(1, std::min<long>((HW + R * 16 - 1) / (R * 16), 1024));
+  dim3 rgrid(xblocks, ygroups, N);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act, cpg),
+             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act, cpg),
+             "instnorm_act_bwd");
+  if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
+  dim3 grid(grid_for(HW * cpr, 2048), N);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act),
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act),
+             "instnorm_act_bwd");
+  return p2phd::check_launch("instnorm_act_bwd(apply)");
+}
+
+extern "C" int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream) {
+  if (n_elems == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(g && a && dx, "act_bwd: null pointer");
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  P2PHD_REQUIRE(n_elems % epp == 0, "act_bwd: element count must be a multiple of %d", epp);
+  const long np = n_elems / epp;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid_for(np)), dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dx, np, act),
+             hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid_for(np)), dim3(256), 0, st, (const float*)g, (const float*)a, (float*)dx, np, act),
+             "act_bwd");
+  return p2phd::check_launch("act_bwd");
+}
+
+extern "C" int p2phd_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+  const int Cp = (C + 7) & ~7;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (N == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(x && y && H >= 1 && W >= 1, "avgpool_fwd: bad arguments");
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const long work = (long)N * Ho * Wo * (Cp / epp);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(avgpool_fwd_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, Ho, Wo, Cp),
+             hipLaunchKernelGGL(avgpool_fwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, Ho, Wo, Cp),
+             "avgpool_fwd");
+  return p2phd::check_launch("avgpool_fwd");
+}
+
+extern "C" int p2phd_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, void* stream) {
+  const int Cp = (C + 7) & ~7;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  if (N == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(dy && dx && H >= 1 && W >= 1, "avgpool_bwd: bad arguments");
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const long work = (long)N * H * W * (Cp / epp);
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(avgpool_bwd_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, Ho, Wo, Cp),
+             hipLaunchKernelGGL(avgpool_bwd_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)dy, (float*)dx, N, H, W, Ho, Wo, Cp),
+             "avgpool_bwd");
+  return p2phd::check_launch("avgpool_bwd");
+}
+
+extern "C" int p2phd_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream) {
+  if ((long)N * C * HW == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(src && dst && ch_off >= 0 && ch_off + C <= Cp, "nchw_to_nhwc: bad arguments");
+  const long work = (long)N * C * HW;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, src, (bf16_t*)dst, N, C, (long)HW, Cp, ch_off),
+             hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, src, (float*)dst, N, C, (long)HW, Cp, ch_off),
+             "nchw_to_nhwc");
+  return p2phd::check_launch("nchw_to_nhwc");
+}
+
+extern "C" int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream) {
+  if ((long)N * C * HW == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(src && dst && ch_off >= 0 && ch_off + C <= Cp, "nhwc_to_nchw: bad arguments");
+  const long work = (long)N * C * HW;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, (long)HW, Cp, ch_off),
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)src, dst, N, C, (long)HW, Cp, ch_off),
+             "nhwc_to_nchw");
+  return p2phd::check_launch("nhwc_to_nchw");
+}

@@ -1,0 +1,143 @@
+"""GPU parity of the fused conv block (HIP implicit-GEMM conv + InstanceNorm/act kernels, through the C ABI)
+against the same layer expressed with torch-CPU fp32 functional ops (the oracle's building blocks), for every
+conv geometry the generator / discriminator use: forward, input gradient, weight and bias gradients."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, assert_grad_close
+
+pytestmark = pytest.mark.gpu
+
+ACT = {0: lambda v: v, 1: lambda v: F.leaky_relu(v, 0.2), 2: torch.tanh, 3: F.relu}
+
+# name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, (N,H,W), residual
+CASES = [
+    ("c7_reflect_in_relu", 2, 8, 7, 1, 3, 1, False, 0, True, 3, (2, 20, 12), False),      # G first layer
+    ("c7_reflect_tanh", 8, 2, 7, 1, 3, 1, False, 0, False, 2, (2, 12, 20), False),        # G head
+    ("c3_s2_in_relu", 8, 16, 3, 2, 1, 0, False, 0, True, 3, (2, 16, 10), False),          # downsample
+    ("c3_s2_odd", 16, 24, 3, 2, 1, 0, False, 0, True, 3, (1, 15, 9), False),
+    ("c3_reflect_in_relu", 16, 16, 3, 1, 1, 1, False, 0, True, 3, (2, 6, 5), False),      # resblock conv 1
+    ("c3_reflect_in_res", 16, 16, 3, 1, 1, 1, False, 0, True, 0, (2, 6, 5), True),        # resblock conv 2 + skip
+    ("c3_reflect_2x2", 32, 32, 3, 1, 1, 1, False, 0, True, 3, (2, 2, 2), False),          # smallest trunk
+    ("ct3_s2_in_relu", 16, 8, 3, 2, 1, 0, True, 1, True, 3, (2, 5, 7), False),            # upsample
+    ("c4_s2_lrelu", 4, 8, 4, 2, 2, 0, False, 0, False, 1, (2, 16, 10), False),            # D layer 0
+    ("c4_s2_in_lrelu", 8, 16, 4, 2, 2, 0, False, 0, True, 1, (2, 9, 7), False),           # D layer 1-2
+    ("c4_s1_in_lrelu", 16, 32, 4, 1, 2, 0, False, 0, True, 1, (2, 5, 4), False),          # D layer 3
+    ("c4_s1_to1", 32, 1, 4, 1, 2, 0, False, 0, False, 0, (2, 6, 5), False),               # D head
+    ("wide_k200_c136", 136, 200, 3, 1, 1, 1, False, 0, True, 3, (1, 12, 12), False),      # >1 N tile, K not /64
+    ("big_m_tiles", 8, 8, 3, 1, 1, 0, False, 0, True, 3, (2, 40, 33), False),             # several M tiles + tail
+]
+
+
+def _oracle(x, w, b, res, c):
+    name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, _, _ = c
+    if transposed:
+        y = F.conv_transpose2d(x, w, b, stride=stride, padding=pad, output_padding=opad)
+    elif pad_mode:
+        y = F.conv2d(F.pad(x, (pad,) * 4, mode="reflect"), w, b, stride=stride)
+    else:
+        y = F.conv2d(x, w, b, stride=stride, padding=pad)
+    if norm:
+        y = F.instance_norm(y, eps=1e-5)
+    y = ACT[act](y)
+    if res is not None:
+        y = y + res
+    return y
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_block(case, dtype, tol):
+    from pix2pixhdaudiosr_amd import _ops
+    name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, (N, H, W), use_res = case
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(N, cin, H, W, generator=g)
+    wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+    w = torch.randn(wshape, generator=g) * 0.1
+    b = torch.randn(cout, generator=g) * 0.1
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
+    res_o = None
+    yo_shape = _oracle(x, w, b, None, case).shape
+    if use_res:
+        res_o = torch.randn(yo_shape, generator=g).requires_grad_(True)
+    yo = _oracle(xo, wo, bo, res_o, case)
+    cot = torch.randn(yo.shape, generator=g)
+    gro = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo] + ([res_o] if use_res else []))
+
+    spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act)
+    xd = x.cuda().requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    bd = b.cuda().requires_grad_(True)
+    xp = _ops.ToPhysical.apply(dtype, xd)
+    rp = None
+    if use_res:
+        rd = res_o.detach().cuda().requires_grad_(True)
+        rp = _ops.ToPhysical.apply(dtype, rd)
+    yp = _ops.conv_block(xp, wd, bd, spec, rp)
+    assert yp.shape[-1] == _ops.cpitch(cout)
+    assert float(yp[..., cout:].float().abs().max()) == 0.0 if yp.shape[-1] > cout else True   # pad channels stay zero
+    y = _ops.FromPhysical.apply(yp, cout)
+    assert tuple(y.shape) == tuple(yo.shape)
+    assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < tol, name
+    grd = torch.autograd.grad((y * cot.cuda()).sum(), [xd, wd, bd] + ([rd] if use_res else []))
+    gt = tol * 3
+    assert rel_err(grd[0].cpu().numpy(), gro[0].numpy()) < gt, name + " dgrad"
+    assert_grad_close(name + ".weight", grd[1].cpu().numpy(), gro[1].numpy(), rtol=gt)
+    bias_floor = 2e-3 if dtype == torch.float32 else 0.5
+    assert_grad_close(name + ".bias", grd[2].cpu().numpy(), gro[2].numpy(), rtol=gt, bias_floor=bias_floor if norm else 1e-6 + gt)
+    if use_res:
+        assert rel_err(grd[3].cpu().numpy(), gro[3].numpy()) < gt
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-6), (torch.bfloat16, 1e-2)])
+def test_avgpool(dtype, tol):
+    from pix2pixhdaudiosr_amd import _ops
+    for (N, C, H, W) in [(2, 4, 16, 10), (1, 2, 7, 5), (2, 16, 2, 2)]:
+        x = torch.randn(N, C, H, W)
+        xo = x.clone().requires_grad_(True)
+        yo = F.avg_pool2d(xo, 3, stride=2, padding=[1, 1], count_include_pad=False)
+        cot = torch.randn_like(yo)
+        (gxo,) = torch.autograd.grad((yo * cot).sum(), xo)
+        xd = x.cuda().requires_grad_(True)
+        y = _ops.FromPhysical.apply(_ops.avgpool(_ops.ToPhysical.apply(dtype, xd), C), C)
+        assert tuple(y.shape) == tuple(yo.shape)
+        assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < tol
+        (gx,) = torch.autograd.grad((y * cot.cuda()).sum(), xd)
+        assert rel_err(gx.cpu().numpy(), gxo.numpy()) < tol * 2
+
+
+def test_losses_and_adam():
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    torch.manual_seed(0)
+    a = torch.randn(2, 3, 5, 4)
+    b = torch.randn(2, 3, 5, 4)
+    for dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 2e-2)):
+        ad = a.cuda().requires_grad_(True)
+        ap = _ops.ToPhysical.apply(dtype, ad)
+        bp = _ops.ToPhysical.apply(dtype, b.cuda())
+        l_mse = _ops.mse_const_loss(ap, 3, 1.0)
+        l_l1 = _ops.l1_loss(ap, bp, 3, 2.5)
+        ao = a.clone().requires_grad_(True)
+        ro_mse = F.mse_loss(ao, torch.ones_like(ao))
+        ro_l1 = 2.5 * F.l1_loss(ao, b)
+        assert abs(float(l_mse) - float(ro_mse)) < tol * 5 and abs(float(l_l1) - float(ro_l1)) < tol * 5
+        (gd,) = torch.autograd.grad(l_mse * 3.0 + l_l1, ad)
+        (go,) = torch.autograd.grad(ro_mse * 3.0 + ro_l1, ao)
+        assert rel_err(gd.cpu().numpy(), go.numpy()) < max(tol * 10, 1e-4)
+    # Adam vs torch.optim.Adam over 3 steps
+    n = 1003
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
+    p = p0.clone().cuda()
+    # 16-byte aligned flat buffers
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n)
+        ref.grad = gr.clone()
+        opt.step()
+        _lib.check(_lib.lib().p2phd_adam_step(_lib.ptr(p), _lib.ptr(gr.cuda()), _lib.ptr(m), _lib.ptr(v), n, 2e-4, 0.5, 0.999, 1e-8,
+                                              step, 1.0, _lib.stream_ptr()))
+    assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6

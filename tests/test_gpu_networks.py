@@ -1,0 +1,75 @@
+"""GPU parity of the generator / discriminator (HIP path behind the reference's module API) against golden
+vectors produced by the reference's own modules (tools/gen_golden.py): outputs, input gradient, every
+parameter gradient, fp32 mode at 1e-4 (north_star tolerance); bf16 mode against a looser stated bound."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, assert_grad_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(net, g, tag):
+    sd = {str(k): torch.from_numpy(g[f"{tag}_p_{k}"]) for k in g[f"{tag}_keys"]}
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    return net.cuda()
+
+
+G_CASES = {
+    "Gglobal": (2, 2, 8, "global", 2, 2, 0, 0),
+    "Gglobal_nd4": (2, 2, 2, "global", 4, 1, 0, 0),
+    "Glocal": (2, 2, 4, "local", 2, 2, 1, 1),
+    "Glocal2": (2, 2, 4, "local", 1, 1, 2, 1),
+}
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-4, 3e-4), (torch.bfloat16, 5e-2, 1.5e-1)])
+@pytest.mark.parametrize("tag", list(G_CASES))
+def test_generator(golden_networks, tag, dtype, tol, gtol):
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    g = golden_networks
+    net = _load(PN.define_G(*G_CASES[tag], "instance", [], dtype=dtype, verbose=False), g, tag)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda().requires_grad_(True)
+    y = net(x)
+    assert tuple(y.shape) == g[f"{tag}_y"].shape and y.dtype == torch.float32
+    assert rel_err(y.detach().cpu().numpy(), g[f"{tag}_y"]) < tol
+    params = dict(net.named_parameters())
+    grads = torch.autograd.grad((y * torch.from_numpy(g[f"{tag}_cot"]).cuda()).sum(), [x] + list(params.values()))
+    assert rel_err(grads[0].cpu().numpy(), g[f"{tag}_gx"]) < gtol
+    for k, gr in zip(params.keys(), grads[1:]):
+        assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol,
+                          bias_floor=2e-3 if dtype == torch.float32 else 0.5)
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-4, 3e-4), (torch.bfloat16, 5e-2, 1.5e-1)])
+@pytest.mark.parametrize("tag,gi", [("D", True), ("Dnofeat", False)])
+def test_discriminator(golden_networks, tag, gi, dtype, tol, gtol):
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    g = golden_networks
+    net = _load(PN.define_D(4, 8, 3, "instance", False, 2, gi, [], dtype=dtype, verbose=False), g, tag)
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda().requires_grad_(True)
+    res = net(x)
+    assert [len(s) for s in res] == list(g[f"{tag}_nfeat"])
+    flat = [f for s in res for f in s]
+    tot = 0
+    for i, f in enumerate(flat):
+        assert tuple(f.shape) == g[f"{tag}_f{i}"].shape, i          # odd sizes 257x129 ... of the k4 p2 convs
+        assert rel_err(f.detach().float().cpu().numpy(), g[f"{tag}_f{i}"]) < tol, i
+        tot = tot + (f.float() * torch.from_numpy(g[f"{tag}_c{i}"]).cuda()).sum()
+    params = dict(net.named_parameters())
+    grads = torch.autograd.grad(tot, [x] + list(params.values()))
+    assert rel_err(grads[0].cpu().numpy(), g[f"{tag}_gx"]) < gtol
+    for k, gr in zip(params.keys(), grads[1:]):
+        assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol,
+                          bias_floor=2e-3 if dtype == torch.float32 else 0.5)
+
+
+def test_gan_loss_kat(golden_networks):
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    g = golden_networks
+    crit = PN.GANLoss(use_lsgan=True)
+    pred = [[torch.from_numpy(g["ganloss_p0"]).cuda()], [torch.from_numpy(g["ganloss_p1"]).cuda()]]
+    assert abs(float(crit(pred, True)) - float(g["ganloss_real"])) < 1e-5
+    assert abs(float(crit(pred, False)) - float(g["ganloss_fake"])) < 1e-5
