@@ -1,0 +1,313 @@
+"""Pix2PixHDModel with the reference's public surface (models/pix2pixHD_model.py), driving the HIP hot path:
+MDCT4 -> dB/sign encoding -> generator -> 3x multiscale discriminator -> LSGAN + feature-matching losses.
+
+What is the same as the reference: constructor-less ``initialize(opt)``; ``forward(lr_audio, inst, hr_audio,
+feat, infer)`` returning ``[filtered losses, sr or None]``; ``inference``; ``encode_input`` (8-tuple);
+``to_spectro`` / ``denormalize`` / ``to_audio``; ``loss_names``; ``optimizer_G`` / ``optimizer_D``;
+``save`` / ``update_fixed_params`` / ``update_learning_rate``; checkpoint file names and state_dict keys.
+
+Deliberate differences:
+  * the transform is MDCT4/IMDCT4 (n_fft/2 bins -- the 512x256 geometry of BASELINE.json); the shipped
+    reference hard-codes MDCT2 (pix2pixHD_model.py:37-40) and invites the swap in README.md:133;
+  * MDCT output is fp32 (the reference's complex128 twiddles make it fp64, which its own fp32 convs reject);
+  * only the configuration the published runs use is on the path: explicit_encoding, mask_mode in
+    {None, 'mode2'}, LSGAN, no VGG / hifigan / time-domain discriminator / feature encoder;
+  * the D weight gradients of the G-loss pass are not computed (train.py:176 zeroes them unread);
+  * the per-step device->host copies of pix2pixHD_model.py:418-428 are deferred to get_current_visuals();
+  * ``--fp16`` selects bf16 MFMA compute with fp32 master weights instead of fp16 autocast + GradScaler;
+  * ``.module`` returns the model itself (create_model never wraps in DataParallel, see models.py).
+"""
+import numpy as np
+import torch
+
+from .. import _lib, _ops
+from ..optim import FlatAdam
+from ..util.util import kbdwin
+from . import networks
+from .base_model import BaseModel
+from .mdct import MDCT4, IMDCT4
+
+
+def _opt(opt, name, default):
+    return getattr(opt, name, default)
+
+
+class Pix2PixHDModel(BaseModel):
+    def name(self):
+        return 'Pix2PixHDModel'
+
+    @property
+    def module(self):
+        return self
+
+    def init_loss_filter(self, use_gan_feat_loss, use_vgg_loss, use_match_loss, use_time_loss):
+        flags = (True, use_gan_feat_loss, use_vgg_loss, use_match_loss, use_time_loss, use_time_loss, use_time_loss, True, True)
+
+        def loss_filter(g_gan, g_gan_feat, g_vgg, g_mat, g_gan_t, d_real_t, d_fake_t, d_real, d_fake):
+            return [l for (l, f) in zip((g_gan, g_gan_feat, g_vgg, g_mat, g_gan_t, d_real_t, d_fake_t, d_real, d_fake), flags) if f]
+        return loss_filter
+
+    def _check_supported(self, opt):
+        unsupported = []
+        if not _opt(opt, 'explicit_encoding', False):
+            unsupported.append("explicit_encoding must be set (the published configuration)")
+        if _opt(opt, 'mask_mode', None) not in (None, 'mode2'):
+            unsupported.append("mask_mode must be None or 'mode2'")
+        for flag in ('use_hifigan_D', 'use_time_D', 'use_match_loss', 'instance_feat', 'label_feat'):
+            if _opt(opt, flag, False):
+                unsupported.append("--%s is outside the HIP hot path" % flag)
+        if not _opt(opt, 'no_vgg_loss', True):
+            unsupported.append("VGG loss (deprecated in the reference) needs --no_vgg_loss")
+        if not _opt(opt, 'no_instance', True):
+            unsupported.append("instance maps are deprecated: use --no_instance")
+        if _opt(opt, 'no_lsgan', False):
+            unsupported.append("only the LSGAN criterion is implemented")
+        if _opt(opt, 'label_nc', 0) != 0:
+            unsupported.append("label_nc must be 0 (audio)")
+        if _opt(opt, 'pool_size', 0) != 0:
+            unsupported.append("pool_size must be 0 (the reference default; ImagePool is a no-op then)")
+        if unsupported:
+            raise NotImplementedError("Pix2PixHDModel (HIP path): " + "; ".join(unsupported))
+
+    def initialize(self, opt):
+        BaseModel.initialize(self, opt)
+        self._check_supported(opt)
+        if not torch.cuda.is_available() or len(self.gpu_ids) == 0:
+            raise RuntimeError("this model runs on the MI355X HIP kernels only; pass gpu_ids=[0] (no CPU path)")
+        self.isTrain = opt.isTrain
+        self.use_features = False
+        self.gen_features = False
+        self.compute_dtype = torch.bfloat16 if _opt(opt, 'fp16', False) else torch.float32
+        input_nc = opt.input_nc
+
+        ##### transform
+        self.up_ratio = opt.hr_sampling_rate / opt.lr_sampling_rate
+        self.window = kbdwin(opt.win_length).to(self.device)
+        kw = dict(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=self.window, device=self.device)
+        self._mdct = MDCT4(**kw)
+        self._imdct = IMDCT4(**kw)
+
+        ##### networks
+        verbose = _opt(opt, 'verbose', False)
+        self.netG = networks.define_G(input_nc, opt.output_nc, opt.ngf, opt.netG, opt.n_downsample_global,
+                                      opt.n_blocks_global, opt.n_local_enhancers, opt.n_blocks_local, opt.norm,
+                                      gpu_ids=self.gpu_ids, dtype=self.compute_dtype, verbose=verbose)
+        if self.isTrain:
+            self.netD = networks.define_D(input_nc + opt.output_nc, opt.ndf, opt.n_layers_D, opt.norm, False, opt.num_D,
+                                          not opt.no_ganFeat_loss, gpu_ids=self.gpu_ids, dtype=self.compute_dtype,
+                                          verbose=verbose)
+        if verbose:
+            print('---------- Networks initialized -------------')
+
+        if not self.isTrain or _opt(opt, 'continue_train', False) or _opt(opt, 'load_pretrain', ''):
+            pretrained_path = '' if not self.isTrain else opt.load_pretrain
+            self.load_network(self.netG, 'G', opt.which_epoch, pretrained_path)
+            if self.isTrain:
+                self.load_network(self.netD, 'D', opt.which_epoch, pretrained_path)
+
+        if self.isTrain:
+            self.old_lr = opt.lr
+            self.loss_filter = self.init_loss_filter(not opt.no_ganFeat_loss, False, False, False)
+            self.criterionGAN = networks.GANLoss(use_lsgan=True, tensor=self.Tensor)
+            self.criterionFeat = networks.FeatLoss()
+            self.loss_names = self.loss_filter('G_GAN', 'G_GAN_Feat', 'G_VGG', 'G_mat', 'G_GAN_t', 'D_real_t', 'D_fake_t', 'D_real', 'D_fake')
+
+            if _opt(opt, 'niter_fix_global', 0) > 0:
+                prefix = 'model' + str(opt.n_local_enhancers)
+                params = [v for k, v in self.netG.named_parameters() if k.startswith(prefix)]
+                print('------------- Only training the local enhancer network (for %d epochs) ------------' % opt.niter_fix_global)
+            else:
+                params = list(self.netG.parameters())
+            if verbose:
+                print('Total number of parameters of G: %d' % (sum([param.numel() for param in params])))
+            self.optimizer_G = FlatAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
+            params = list(self.netD.parameters())
+            if verbose:
+                print('Total number of parameters of D: %d' % (sum([param.numel() for param in params])))
+            self.optimizer_D = FlatAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
+        self._visual = None
+
+    # ------------------------------------------------------------------------------------------
+    # spectrogram codec (HIP: csrc/spectro.hip)
+    # ------------------------------------------------------------------------------------------
+    def to_spectro(self, audio, mask=False, noise=None):
+        """audio [B,T] -> (log_spectro [B,2,bins,frames] in [0,1], pha [B,1,bins,frames], norm dict).
+        ``noise`` ([B,2,mask_rows,frames]) replaces the torch.randn draw of pix2pixHD_model.py:202 when given."""
+        spec = self._mdct(audio.to(self.device))                            # [B, frames, bins] f32
+        B, Fr, M = spec.shape
+        L = _lib.lib()
+        log_spectro = torch.empty((B, 2, M, Fr), dtype=torch.float32, device=spec.device)
+        pha = torch.empty((B, 1, M, Fr), dtype=torch.float32, device=spec.device)
+        norm8 = torch.zeros(8, dtype=torch.float32, device=spec.device)
+        partials = torch.empty(L.p2phd_spectro_partials_floats(B, Fr, M), dtype=torch.float32, device=spec.device)
+        mask_rows = 0
+        if mask:
+            mask_rows = int(M * (1 - 1 / self.up_ratio))                    # pix2pixHD_model.py:199
+            if self.opt.mask_mode == 'mode2':
+                if noise is None:
+                    noise = torch.randn(B, 2, mask_rows, Fr, device=spec.device)
+                noise = noise.to(spec.device).float().contiguous()
+                assert tuple(noise.shape) == (B, 2, mask_rows, Fr)
+            else:
+                noise = None
+        else:
+            noise = None
+        _lib.check(L.p2phd_spectro_encode(_lib.ptr(spec), B, Fr, M, float(self.opt.alpha), float(self.opt.min_value),
+                                          mask_rows, _lib.ptr(noise), _lib.ptr(log_spectro), _lib.ptr(pha), _lib.ptr(norm8),
+                                          _lib.ptr(partials), _lib.stream_ptr()), "spectro_encode")
+        norm = {'min': norm8[0], 'max': norm8[1], 'mean': norm8[2], 'std': norm8[3], 'frames': None, '_minmax': norm8[:2]}
+        return log_spectro, pha, norm
+
+    def _minmax(self, norm_param):
+        mm = norm_param.get('_minmax')
+        if mm is None:
+            mm = torch.stack([torch.as_tensor(norm_param['min']).float().reshape(()),
+                              torch.as_tensor(norm_param['max']).float().reshape(())]).to(self.device)
+        return mm.contiguous()
+
+    def denormalize(self, log_spectro, norm_param):
+        mm = self._minmax(norm_param)
+        s = torch.abs(log_spectro) * (mm[1] - mm[0]) + mm[0]
+        return 10.0 * torch.pow(10.0, s * 0.05) - self.opt.min_value        # DB_to_amplitude(s, 10, 0.5) - min_value
+
+    def to_audio(self, log_spectro, norm_param, pha=None):
+        x = log_spectro.to(self.device).float().contiguous()
+        B, _, M, Fr = x.shape
+        spec = torch.empty((B, Fr, M), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().p2phd_spectro_decode(_lib.ptr(x), _lib.ptr(self._minmax(norm_param)), B, Fr, M,
+                                                   float(self.opt.alpha), float(self.opt.min_value), _lib.ptr(spec),
+                                                   _lib.stream_ptr()), "spectro_decode")
+        return np.sqrt(self.up_ratio - 1) * self._imdct(spec)
+
+    def to_frames(self, log_spectro, norm_param):
+        raise NotImplementedError("to_frames (IDCT per frame, use_match_loss) is a next-row item (SURVEY 8f.1)")
+
+    def encode_input(self, lr_audio, inst_map=None, hr_audio=None, feat_map=None, noise=None):
+        with torch.no_grad():
+            if hr_audio is not None:
+                hr_spectro, hr_pha, hr_norm_param = self.to_spectro(hr_audio, mask=False)
+            else:
+                hr_spectro = hr_pha = hr_norm_param = None
+            lr_spectro, lr_pha, lr_norm_param = self.to_spectro(lr_audio, mask=bool(_opt(self.opt, 'mask', False)), noise=noise)
+        return lr_spectro, lr_pha, hr_spectro, hr_pha, feat_map, inst_map, hr_norm_param, lr_norm_param
+
+    # ------------------------------------------------------------------------------------------
+    # losses on physical tensors
+    # ------------------------------------------------------------------------------------------
+    def _D(self, lr_spectro, other):
+        """netD on cat(lr, other) -> list[num_D] of list of (physical tensor, channels)."""
+        return self.netD.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro, other))
+
+    @staticmethod
+    def _gan(pred, target):
+        loss = 0
+        for scale in pred:
+            t, c = scale[-1]
+            loss = loss + _ops.mse_const_loss(t, c, target)
+        return loss
+
+    def discriminate_F(self, input_label, test_image, use_pool=False):
+        return self.netD.forward(torch.cat((input_label, test_image.detach()), dim=1))
+
+    def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
+        lr_spectro, lr_pha, hr_spectro, hr_pha, _, _, hr_norm_param, lr_norm_param = \
+            self.encode_input(lr_audio, inst, hr_audio, feat, noise=noise)
+
+        sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro))
+        sr_result = _ops.FromPhysical.apply(sr_phys, self.opt.output_nc)
+
+        # fake detection (detached: no gradient to G), real detection
+        pred_fake_pool = self._D(lr_spectro, sr_result.detach())
+        loss_D_fake = self._gan(pred_fake_pool, 0.0)
+        pred_real = self._D(lr_spectro, hr_spectro)
+        loss_D_real = self._gan(pred_real, 1.0)
+
+        # GAN loss through D into G; D's weight gradients of this pass are never used (train.py:176)
+        with _ops.no_weight_grad():
+            pred_fake = self._D(lr_spectro, sr_result)
+        loss_G_GAN = self._gan(pred_fake, 1.0)
+
+        loss_G_GAN_Feat = 0
+        if not self.opt.no_ganFeat_loss:
+            feat_weights = 4.0 / (self.opt.n_layers_D + 1)
+            D_weights = 1.0 / self.opt.num_D
+            for i in range(self.opt.num_D):
+                for j in range(len(pred_fake[i]) - 1):
+                    (a, c), (b, _) = pred_fake[i][j], pred_real[i][j]
+                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, D_weights * feat_weights * self.opt.lambda_feat)
+
+        # visuals are fetched lazily (no device->host copy in the step)
+        self._visual = (lr_spectro, sr_result.detach(), hr_spectro, hr_pha)
+
+        return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, 0, 0, 0, 0, loss_D_real, loss_D_fake),
+                None if not infer else sr_result]
+
+    def inference(self, lr_audio, inst, noise=None):
+        lr_spectro, lr_pha, _, _, _, _, _, lr_norm_param = self.encode_input(lr_audio, inst, None, noise=noise)
+        with torch.no_grad():
+            sr_spectro = self.netG.forward(lr_spectro)
+        return sr_spectro, lr_pha, lr_norm_param, lr_spectro
+
+    # ------------------------------------------------------------------------------------------
+    # one full optimisation step (train.py:148-184) with the all-reduce of the G gradients overlapped
+    # with the D backward pass; result-identical to calling backward/step in train.py's order
+    # ------------------------------------------------------------------------------------------
+    def train_step(self, lr_audio, hr_audio, noise=None):
+        losses, _ = self.forward(lr_audio, None, hr_audio, None, infer=False, noise=noise)
+        ld = dict(zip(self.loss_names, losses))
+        loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
+        loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0)
+        self.optimizer_G.zero_grad()
+        self.optimizer_D.zero_grad()
+        g_params = [p for p in self.optimizer_G._params]
+        d_params = [p for p in self.optimizer_D._params]
+        # G backward: only G parameters receive gradients (inputs= keeps autograd off the D leaves)
+        loss_G.backward(inputs=g_params)
+        self.optimizer_G.reduce_gradients_async()
+        loss_D.backward(inputs=d_params)
+        self.optimizer_D.reduce_gradients_async()
+        self.optimizer_G.step()
+        self.optimizer_D.step()
+        return ld
+
+    def save(self, which_epoch):
+        self.save_network(self.netG, 'G', which_epoch, self.gpu_ids)
+        self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
+
+    def update_fixed_params(self):
+        self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        if _opt(self.opt, 'verbose', False):
+            print('------------ Now also finetuning global generator -----------')
+
+    def update_learning_rate(self):
+        lrd = self.opt.lr / self.opt.niter_decay
+        lr = self.old_lr - lrd
+        for opt in (self.optimizer_D, self.optimizer_G):
+            for param_group in opt.param_groups:
+                param_group['lr'] = lr
+        if _opt(self.opt, 'verbose', False):
+            print('update learning rate: %f -> %f' % (self.old_lr, lr))
+        self.old_lr = lr
+
+    def get_current_visuals(self):
+        """Sample-0 spectrograms as numpy arrays (the reference renders them with matplotlib; that
+        observability layer is out of scope, the data it plots is here)."""
+        if self._visual is None:
+            return {}
+        lr_s, sr, hr_s, hr_pha = self._visual
+        out = {'lable_spectro': 0.5 * (lr_s[0, 0] + lr_s[0, 1]).cpu().numpy(),
+               'generated_spectro': 0.5 * (sr[0, 0] + sr[0, 1]).cpu().numpy()}
+        if hr_s is not None:
+            out['real_spectro'] = 0.5 * (hr_s[0, 0] + hr_s[0, 1]).cpu().numpy()
+        sr_pha = torch.sign(sr[0, 0] - sr[0, 1])
+        out['generated_pha'] = sr_pha.cpu().numpy()
+        if hr_pha is not None:
+            out['real_pha'] = hr_pha[0, 0].cpu().numpy()
+            out['lable_pha'] = (hr_pha[0, 0] - sr_pha).cpu().numpy()
+        return out
+
+
+class InferenceModel(Pix2PixHDModel):
+    def forward(self, inp):
+        label, inst = inp
+        return self.inference(label, inst)

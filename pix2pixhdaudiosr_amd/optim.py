@@ -1,0 +1,89 @@
+"""Flat-buffer Adam on the HIP kernel p2phd_adam_step, with the torch.optim.Optimizer surface train.py uses
+(param_groups[...]['lr'], zero_grad(), step(), state_dict()).
+
+MI355X-first layout: all parameters of one network live in ONE contiguous fp32 buffer and all their gradients in
+another.  That makes the optimiser a single HBM-bound launch and the data-parallel exchange a single (or a few
+large) RCCL all-reduce over xGMI instead of one collective per layer.  ``nn.Parameter`` objects keep their
+identity: their storage is re-pointed at slices of the flat buffer, so ``state_dict``/checkpoints are unchanged.
+Update rule = torch.optim.Adam(lr, betas, eps=1e-8), which is what the reference builds
+(models/pix2pixHD_model.py:131,140).
+"""
+import torch
+
+from . import _lib, _ops
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, process_group=None):
+        params = [p for p in params]
+        if not params:
+            raise ValueError("FlatAdam got an empty parameter list")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise _lib.P2PHDError("FlatAdam runs on the GPU only (no CPU fallback)")
+        sizes = [p.numel() for p in params]
+        # 16-byte aligned slices so every parameter / gradient view can be read with float4
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 3) & ~3
+        self._params, self._offs, self._total = params, offs, total
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                n = p.numel()
+                self.flat_p[o:o + n].copy_(p.detach().reshape(-1).float())
+                p.data = self.flat_p[o:o + n].view(p.shape)
+        self._install_grad_views()
+        self.step_count = 0
+        self.process_group = process_group
+        self.world_size = 1
+        self._pending = None
+        _ops.bump_weight_epoch()
+
+    def _install_grad_views(self):
+        for p, o in zip(self._params, self._offs):
+            v = self.flat_g[o:o + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                p.grad = v
+
+    def zero_grad(self, set_to_none=False):
+        # gradients stay views of the flat buffer; one memset instead of one per tensor
+        self.flat_g.zero_()
+        self._install_grad_views()
+
+    # ---- data parallel: one summing all-reduce of the whole gradient buffer over RCCL ----
+    def enable_data_parallel(self, world_size, process_group=None):
+        self.world_size = int(world_size)
+        self.process_group = process_group
+
+    def reduce_gradients_async(self):
+        """Start the gradient all-reduce (call right after backward); step() waits for it."""
+        if self.world_size > 1 and self._pending is None:
+            import torch.distributed as dist
+            self._install_grad_views()
+            self._pending = dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closures are not supported")
+        self._install_grad_views()
+        if self.world_size > 1:
+            self.reduce_gradients_async()
+            self._pending.wait()
+            self._pending = None
+        g = self.param_groups[0]
+        self.step_count += 1
+        b1, b2 = g["betas"]
+        _lib.check(_lib.lib().p2phd_adam_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
+                                              _lib.ptr(self.exp_avg_sq), self._total, float(g["lr"]), float(b1), float(b2),
+                                              float(g["eps"]), self.step_count, 1.0 / self.world_size, _lib.stream_ptr()),
+                   "adam_step")
+        _ops.bump_weight_epoch()
