@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- MDCT spectrogram frames/s through one full GAN training step on MI355X.
+
+Step (= train.py:148-184 of the reference): MDCT4 encode of hr + lr audio -> dB/sign encoding -> GlobalGenerator
+forward -> MultiscaleDiscriminator x3 -> LSGAN + feature-matching losses -> G backward -> D backward -> Adam x2,
+on synthetic audio already resident in HBM.  Workload = BASELINE.json configs[1]: ngf=48, n_local_enhancers=0
+(netG 'global', 4 down-samplings, 9 residual blocks), 512x256 spectrograms (n_fft 1024, hop 512), bf16 MFMA
+compute, per-GPU batch 32.  N > 1: one process per GPU (torch.distributed / RCCL), the minibatch is sharded, the
+flat G / D gradient buffers are all-reduced over xGMI; weak scaling.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel: the implicit-GEMM conv of
+the residual trunk, timed live with HIP events) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FRAMES = 256                      # spectrogram frames per sample at 512x256
+BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd4 nb9 @512x256 (SURVEY 8a probe)
+M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
+
+
+def make_opt(batch, dtype_bf16=True):
+    return SimpleNamespace(
+        gpu_ids=[0], isTrain=True, checkpoints_dir="/tmp/p2phd_bench", name="bench", model="pix2pixHD",
+        input_nc=2, output_nc=2, label_nc=0, hr_sampling_rate=48000, lr_sampling_rate=8000,
+        n_fft=1024, hop_length=512, win_length=1024, center=True, no_instance=True,
+        ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9, n_local_enhancers=0, n_blocks_local=3,
+        norm="instance", no_lsgan=False, ndf=64, n_layers_D=3, num_D=2, no_ganFeat_loss=False,
+        use_hifigan_D=False, use_time_D=False, verbose=False, continue_train=False, load_pretrain="",
+        which_epoch="latest", pool_size=0, lr=0.0002, beta1=0.5, no_vgg_loss=True, use_match_loss=False,
+        niter_fix_global=0, explicit_encoding=True, alpha=0.6, min_value=1e-7, mask=True, mask_mode="mode2",
+        lambda_feat=10.0, fp16=dtype_bf16, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
+
+
+def time_trunk_conv(batch, iters=20):
+    """Average launch duration (HIP events on the launch stream) of the dominant kernel: Conv3x3 768->768 on
+    [B,32,16,768] bf16 behind ReflectionPad2d(1) -- 18 of the 28 generator convs, 80 % of its MACs."""
+    from pix2pixhdaudiosr_amd import _ops
+    import ctypes as C
+    spec = _ops.ConvSpec(768, 768, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    x = torch.randn(batch, 32, 16, 768, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(768, 768, 3, 3, device="cuda") * 0.02)
+    d = spec.desc(batch, 32, 16, torch.bfloat16)
+    wp = spec.packed(w, 0, d)
+    y = torch.empty_like(x)
+    stats = torch.zeros(batch, 768, 2, device="cuda")
+    L = _ops.lib()
+    call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
+                                               _ops.stream_ptr()))
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        call()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * batch * 32 * 16 * 768 * 768 * 9
+    return sec, flops
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))          # a 1-GPU box's CPU share is 16 cores
+
+
+def cpu_baseline(sample_batch=1, steps=1):
+    """The CPU oracle (oracle/model.py full_step: a port of the reference step, validated against the reference in
+    tests/) on the host cores, same workload at a bounded batch."""
+    from oracle import model as OM
+    from oracle import mdct4 as M4
+    opt = OM.default_opt(ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9)
+    torch.set_num_threads(host_cores())
+    pG = OM.N.init_params(OM.netG_spec(opt), seed=1)
+    pD = OM.N.init_params(OM.netD_spec(opt), seed=2)
+    hr, lr, noise = OM.synthetic_batch(sample_batch, opt)
+    w = M4.kbdwin(opt.win_length)
+    sG, sD = {}, {}
+    t0 = time.time()
+    for _ in range(steps):
+        _, pG, pD = OM.full_step(hr, lr, noise, pG, pD, opt, w, sG, sD)
+    dt = (time.time() - t0) / steps
+    return {"value": sample_batch * FRAMES / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle full_step (CPU port of train.py:148-184), same network/config at batch {sample_batch}, "
+                      f"{steps} timed step(s), fp32, {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    from pix2pixhdaudiosr_amd import parallel_state
+
+    torch.manual_seed(1234)                      # same initial weights on every rank (reference default seed)
+    opt = make_opt(a.batch)
+    opt.gpu_ids = [local]
+    model = create_model(opt)
+    if world > 1:
+        parallel_state.enable_data_parallel(model, world)
+    T = (FRAMES - 1) * opt.hop_length
+    g = torch.Generator(device="cuda").manual_seed(1234 + rank)
+    hr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
+    lr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model built, batch {a.batch}, world {world}")
+    for i in range(a.warmup):
+        model.train_step(lr, hr)
+        torch.cuda.synchronize()
+        log(f"warm-up step {i} done")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        model.train_step(lr, hr)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        frames_per_s = world * a.batch * FRAMES * a.steps / dt
+        # minimal result-identical schedule = (3 M_G + 8 M_D) MACs = (6 M_G + 16 M_D) FLOPs per sample
+        step_flops = (6 * M_G + 16 * M_D) * a.batch
+        out = {
+            "metric": "MDCT spectrogram frames/sec (G+D fwd+bwd) at 512x256",
+            "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "configs[1]: ngf=48 n_local_enhancers=0 (GlobalGenerator nd4 nb9) + MultiscaleDiscriminator "
+                                   "num_D=2, 512x256 MDCT4 (n_fft 1024, hop 512), LSGAN + feature matching, Adam, bf16 MFMA",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                       "step_tflops_per_gpu": step_flops / (dt / a.steps) / 1e12,
+                       "step_frac_of_bf16_peak": step_flops / (dt / a.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS},
+        }
+        log(f"timed region done: {ms:.1f} ms/step")
+        sec, flops = time_trunk_conv(a.batch)
+        log(f"trunk conv {sec * 1e6:.1f} us/launch")
+        out["roofline"] = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
+                           "kernel": "gconv_kernel<bf16,BN=128> Conv3x3 768->768 @32x16 (residual trunk)",
+                           "launch_us": sec * 1e6, "flops_per_launch": flops}
+        if world == 1 and not a.no_cpu_baseline:
+            log("cpu baseline (oracle, batch 1) ...")
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -184,3 +184,16 @@ def synthetic_batch(B, opt, seed=1234):
     mask_size = int(bins * (1 - 1 / up))
     noise = torch.randn(B, 2, mask_size, frames, generator=g)
     return hr, lr, noise
+
+
+def full_step(hr, lr, noise, pG, pD, opt, window, stateG, stateD):
+    """One reference-faithful optimisation step on the CPU (train.py:148-184): MDCT4 encode of hr and lr,
+    G forward, three D forwards, LSGAN + feature-matching losses, both backward passes, both Adam updates.
+    Used as the `cpu_baseline` leg of bench.py and by tests; returns (losses, pG, pD)."""
+    with torch.no_grad():
+        hr_s, _, _ = to_spectro(hr, opt, window, mask=False)
+        lr_s, _, _ = to_spectro(lr, opt, window, mask=opt.mask, noise=noise)
+    L, gG, gD = step_grads(pG, pD, lr_s, hr_s, opt)
+    pG = adam_step(dict(pG), gG, stateG, opt.lr, opt.beta1)
+    pD = adam_step(dict(pD), gD, stateD, opt.lr, opt.beta1)
+    return L, pG, pD

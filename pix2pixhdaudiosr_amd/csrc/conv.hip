@@ -13,9 +13,10 @@
 //
 // GEMM view: M = output pixels (tiles never straddle samples), N = output channels, K = taps x channels.
 // 128 x BN x (128 bytes of K) tiles; 4 wavefronts; A (gathered pixels) and B (packed weights, K-contiguous
-// rows) are staged global -> registers -> LDS in 16-byte pieces (coalesced along the channel axis = the
-// frequency-major NHWC inner dimension), double-buffered with the next tile's loads issued before the MFMAs of
-// the current one; LDS rows are 128 B with a 16-byte-chunk XOR swizzle ((row>>1)&7) so the ds_read_b128
+// rows) are staged straight global -> LDS with global_load_lds_dwordx4 in 16-byte pieces (coalesced along the
+// channel axis = the frequency-major NHWC inner dimension), double-buffered with the next tile's loads issued
+// before the MFMAs of the current one; LDS rows are 128 B with a 16-byte-chunk XOR swizzle ((row>>1)&7), applied
+// to the per-lane SOURCE address because the LDS side of a direct load is lane-linear, so the ds_read_b128
 // fragment reads of v_mfma_f32_32x32x16_bf16 are bank-conflict free.  fp32 mode (parity runs) uses the exact
 // v_mfma_f32_32x32x2_f32 on the same tiles.  The epilogue adds bias, accumulates the per-(n,channel) sum and
 // sum of squares InstanceNorm needs (wave reduction + one float atomic per wave and channel), applies an
@@ -72,7 +73,7 @@ constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
 // gather convolution
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BN, int WGM, int WGN, int MR, int NR>
-__global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
+__global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
                                                     const float* __restrict__ bias, const T* __restrict__ addend,
                                                     T* __restrict__ out, float* __restrict__ stats) {
   constexpr int EPP = Elem<T>::EPP;
@@ -82,68 +83,77 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int NB = BN / 32;      // B pieces per thread per step
 
+  // descriptor fields used in loops live in registers (a by-value struct that is captured by reference ends
+  // up in scratch memory)
+  const int Cp = d.Cp_in, KK = d.KK, Wg = d.Wg, T_taps = d.nth * d.ntw, npix = d.Hg * d.Wg;
+  const int Cp_out = d.Cp_out, Kout = d.Kout, act = d.act;
+
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
-  const int T_taps = d.nth * d.ntw;
   int* tab = reinterpret_cast<int*>(smem);
   char* stages = smem + ((T_taps * BM * 4 + 15) & ~15);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
-  const int npix = d.Hg * d.Wg;
   const int mtiles = (npix + BM - 1) / BM;
   const int n = blockIdx.x / mtiles;
   const int p_base = (blockIdx.x - n * mtiles) * BM;
   const int n0 = blockIdx.y * BN;
 
-  // gather table: input pixel index (or -1) per (tap, tile row)
-  for (int e = tid; e < T_taps * BM; e += 256) {
-    const int t = e / BM, r = e - t * BM;
-    const int p = p_base + r;
-    int off = -1;
-    if (p < npix) {
-      const int ho = p / d.Wg, wo = p - ho * d.Wg;
-      const int ta = t / d.ntw, tb = t - ta * d.ntw;
-      int hi = ho * d.sh + d.dh0 + ta * d.dh_step;
-      int wi = wo * d.sw + d.dw0 + tb * d.dw_step;
-      if (d.pad_mode == 1) { hi = reflect_idx(hi, d.Hin); wi = reflect_idx(wi, d.Win); }
-      if (hi >= 0 && hi < d.Hin && wi >= 0 && wi < d.Win) off = (n * d.Hin + hi) * d.Win + wi;
+  {  // gather table: input pixel index (or -1) per (tap, tile row)
+    const int Hin = d.Hin, Win = d.Win, sh = d.sh, sw = d.sw, ntw = d.ntw, pad_mode = d.pad_mode;
+    const int dh0 = d.dh0, dhs = d.dh_step, dw0 = d.dw0, dws = d.dw_step;
+    for (int e = tid; e < T_taps * BM; e += 256) {
+      const int t = e / BM, r = e - t * BM;
+      const int p = p_base + r;
+      int off = -1;
+      if (p < npix) {
+        const int ho = p / Wg, wo = p - ho * Wg;
+        const int ta = t / ntw, tb = t - ta * ntw;
+        int hi = ho * sh + dh0 + ta * dhs;
+        int wi = wo * sw + dw0 + tb * dws;
+        if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
+        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (n * Hin + hi) * Win + wi;
+      }
+      tab[e] = off;
     }
-    tab[e] = off;
   }
   __syncthreads();
 
-  const int chunk = tid & 7, rbase = tid >> 3;
-  const int swz = (chunk ^ ((rbase >> 1) & 7)) << 4;       // rows handled by this thread are rbase + 32 i
-  const int Cp = d.Cp_in;
-  int a_t = (chunk * EPP) / Cp, a_c = (chunk * EPP) % Cp;
-  const T* bptr = wp + (size_t)(n0 + rbase) * d.KK + chunk * EPP;
+  // Direct global -> LDS staging (global_load_lds_dwordx4): one wave instruction fills 8 consecutive 128-byte
+  // tile rows linearly (lane l -> row l>>3, slot l&7).  The bank-conflict swizzle therefore sits on the SOURCE:
+  // the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7), and fragment reads undo it.
+  const int rbase = tid >> 3;                                 // rows rbase + 32 i
+  const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);          // logical 16-byte chunk of the K slab
+  int a_t = (kchunk * EPP) / Cp, a_c = (kchunk * EPP) % Cp;
+  int cur_t = -1;
+  int rowoff[4] = {-1, -1, -1, -1};
+  const T* bsrc = wp + (size_t)(n0 + rbase) * KK + kchunk * EPP;
+  const size_t brow = (size_t)32 * KK;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
-  uint4 ra[4], rb[NB];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
-  auto issue_loads = [&](int step) {
+  auto issue = [&](int stage) {
+    char* A = stages + stage * STAGE + (8 * wave) * kRowBytes;
+    char* B = A + BM * kRowBytes;
+    if (a_t != cur_t) {
+      cur_t = a_t;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rowoff[i] = a_t < T_taps ? tab[a_t * BM + rbase + 32 * i] : -1;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const T* src = zero;
-      if (a_t < T_taps) {
-        const int off = tab[a_t * BM + rbase + 32 * i];
-        if (off >= 0) src = in + (size_t)off * Cp + a_c;
-      }
-      ra[i] = *reinterpret_cast<const uint4*>(src);
+      const T* src = rowoff[i] >= 0 ? in + (size_t)rowoff[i] * Cp + a_c : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(A + 32 * i * kRowBytes), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      rb[i] = *reinterpret_cast<const uint4*>(bptr + (size_t)(32 * i) * d.KK + (size_t)step * BK);
+      __builtin_amdgcn_global_load_lds((gbl_ptr)(bsrc + i * brow), (lds_ptr)(B + 32 * i * kRowBytes), 16, 0, 0);
+    bsrc += BK;
     a_c += BK;
     while (a_c >= Cp) { a_c -= Cp; ++a_t; }
-  };
-  auto write_lds = [&](int stage) {
-    char* A = stages + stage * STAGE;
-    char* B = A + BM * kRowBytes;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(A + (rbase + 32 * i) * kRowBytes + swz) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(B + (rbase + 32 * i) * kRowBytes + swz) = rb[i];
   };
 
   f32x16 acc[MR][NR];
@@ -155,23 +165,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int lr = lane & 31, lh = lane >> 5;
+  // fragment read offsets: row * 128 + ((jj ^ swz(row)) << 4) with jj = 2 ks + lh; swz(row) = (row >> 1) & 7
+  int aoff[MR], asw[MR], boff[NR], bsw[NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i) {
+    const int row = wm * (MR * 32) + i * 32 + lr;
+    aoff[i] = row * kRowBytes; asw[i] = (row >> 1) & 7;
+  }
+#pragma unroll
+  for (int j = 0; j < NR; ++j) {
+    const int row = wn * (NR * 32) + j * 32 + lr;
+    boff[j] = BM * kRowBytes + row * kRowBytes; bsw[j] = (row >> 1) & 7;
+  }
+
   auto compute = [&](int stage) {
-    const char* A = stages + stage * STAGE;
-    const char* B = A + BM * kRowBytes;
+    const char* S = stages + stage * STAGE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int jj = 2 * ks + lh;
       uint4 af[MR], bfr[NR];
 #pragma unroll
-      for (int i = 0; i < MR; ++i) {
-        const int row = wm * (MR * 32) + i * 32 + lr;
-        af[i] = *reinterpret_cast<const uint4*>(A + row * kRowBytes + ((jj ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const uint4*>(S + aoff[i] + ((jj ^ asw[i]) << 4));
 #pragma unroll
-      for (int j = 0; j < NR; ++j) {
-        const int row = wn * (NR * 32) + j * 32 + lr;
-        bfr[j] = *reinterpret_cast<const uint4*>(B + row * kRowBytes + ((jj ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const uint4*>(S + boff[j] + ((jj ^ bsw[j]) << 4));
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -191,14 +207,12 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
     }
   };
 
-  const int nsteps = d.KK / BK;
-  issue_loads(0);
-  write_lds(0);
-  __syncthreads();
+  const int nsteps = KK / BK;
+  issue(0);
+  __syncthreads();                       // emits s_waitcnt vmcnt(0): the LDS-DMA of stage 0 has landed
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) issue_loads(s + 1);
+    if (s + 1 < nsteps) issue((s + 1) & 1);
     compute(s & 1);
-    if (s + 1 < nsteps) write_lds((s + 1) & 1);
     __syncthreads();
   }
 
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
   for (int j = 0; j < NR; ++j) {
     const int col = wn * (NR * 32) + j * 32 + lr;
     const int k = n0 + col;
-    const float bv = (bias != nullptr && k < d.Kout) ? bias[k] : 0.f;
+    const float bv = (bias != nullptr && k < Kout) ? bias[k] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
@@ -218,37 +232,38 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
         const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v = acc[i][j][e] + bv;
         if (p_base + row < npix) { s1 += v; s2 += v * v; }
-        v = apply_act(v, d.act);
+        v = apply_act(v, act);
         *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
       }
     }
     if (stats != nullptr) {
       s1 += __shfl_xor(s1, 32);
       s2 += __shfl_xor(s2, 32);
-      if (lh == 0 && k < d.Kout) {
-        atomicAdd(&stats[2 * ((size_t)n * d.Cp_out + k)], s1);
-        atomicAdd(&stats[2 * ((size_t)n * d.Cp_out + k) + 1], s2);
+      if (lh == 0 && k < Kout) {
+        atomicAdd(&stats[2 * ((size_t)n * Cp_out + k)], s1);
+        atomicAdd(&stats[2 * ((size_t)n * Cp_out + k) + 1], s2);
       }
     }
   }
   __syncthreads();
   constexpr int CPR = BN / EPP;                              // 16-byte pieces per C-tile row
+  const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   for (int q = tid; q < BM * CPR; q += 256) {
     const int row = q / CPR, pc = q - row * CPR;
     const int p = p_base + row;
     const int k = n0 + pc * EPP;
-    if (p >= npix || k >= d.Cp_out) continue;
-    const int ho = p / d.Wg, wo = p - ho * d.Wg;
-    const size_t opix = ((size_t)n * d.Hout + (ho * d.oh_mul + d.oh_off)) * d.Wout + (wo * d.ow_mul + d.ow_off);
+    if (p >= npix || k >= Cp_out) continue;
+    const int ho = p / Wg, wo = p - ho * Wg;
+    const size_t opix = ((size_t)n * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo);
     uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
     if (addend != nullptr) {
-      const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * d.Cp_out + k);
+      const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * Cp_out + k);
       T* vv = reinterpret_cast<T*>(&v);
       const T* aa = reinterpret_cast<const T*>(&a);
 #pragma unroll
       for (int e = 0; e < EPP; ++e) vv[e] = from_f<T>(to_f(vv[e]) + to_f(aa[e]));
     }
-    *reinterpret_cast<uint4*>(out + opix * d.Cp_out + k) = v;
+    *reinterpret_cast<uint4*>(out + opix * Cp_out + k) = v;
   }
 }
 
@@ -258,25 +273,29 @@ __global__ __launch_bounds__(256) void gconv_kernel(GDesc d, const T* __restrict
 //   gather : [N,Hin,Win,Cp_in] the tensor reached through the taps
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
+__global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
                                                     float* __restrict__ dwp, int Cp_r, int steps_per_split, int use_atomic) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int BKP = sizeof(T) == 2 ? 64 : 32;             // pixels per K-step
   constexpr int TM = 128, TN = 128;
-  constexpr int ROWB = TM * (int)sizeof(T) + (sizeof(T) == 2 ? 64 : 0);   // padded LDS row (conflict-free tr reads)
+  constexpr int ROWB = TM * (int)sizeof(T);                 // 256 B (bf16) / 512 B (f32) LDS rows, unpadded
   constexpr int TILE = BKP * ROWB;
-  constexpr int CPR = TM / EPP;                             // pieces per row
-  constexpr int PPT = BKP * CPR / 256;                      // pieces per thread per tile
+  constexpr int CPR = TM / EPP;                             // 16-byte pieces per row: 16 / 32
+  constexpr int PPT = BKP * CPR / 256;                      // pieces per thread per tile (4)
   constexpr int RSTEP = 256 / CPR;                          // row distance between a thread's pieces
+  constexpr int RPW = 64 / CPR;                             // rows one wave instruction fills: 4 / 2
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
+  // loop-resident descriptor fields in registers (see gconv_kernel)
+  const int Hg = d.Hg, Wg = d.Wg, Hin = d.Hin, Win = d.Win, Cpi = d.Cp_in, sh = d.sh, sw = d.sw, pad_mode = d.pad_mode, KK = d.KK;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int j0 = blockIdx.x * TN;                           // first kk column
   const int m0 = blockIdx.y * TM;                           // first output row
-  const int npix = d.Hg * d.Wg;
+  const int npix = Hg * Wg;
   const long P = (long)d.N * npix;
   const int total_steps = (int)((P + BKP - 1) / BKP);
   const int s_begin = blockIdx.z * steps_per_split;
@@ -284,64 +303,71 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict
   if (s_end > total_steps) s_end = total_steps;
   if (s_begin >= s_end) return;
 
-  const int chunk = tid % CPR, rb = tid / CPR;
+  // Direct global -> LDS staging: one wave instruction fills RPW consecutive tile rows linearly.  bf16 tiles are
+  // read back with the transposing ds_read_b64_tr_b16, whose 32-lane half touches 4 pixel rows x 64 B: the 16-byte
+  // chunk index is XORed with (row & 3) << 2 so the four rows land in different quarters of the 256-byte bank row.
+  // As in gconv the swizzle is applied to the per-lane SOURCE column.
+  const int rb = tid / CPR;                                 // tile rows rb + RSTEP * i
+  const int slot = tid % CPR;
+  const int chunk = sizeof(T) == 2 ? (slot ^ ((rb & 3) << 2)) : slot;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
-  // rows-operand: column fixed per thread
-  const int mcol = m0 + chunk * EPP;
+  const int mcol = m0 + chunk * EPP;                        // rows-operand column, fixed per thread
   const bool mvalid = mcol < Cp_r;
-  // gather-operand: (tap, channel) fixed per thread
-  const int kk = j0 + chunk * EPP;
+  const int kk = j0 + chunk * EPP;                          // gather-operand (tap, channel), fixed per thread
   const int T_taps = d.nth * d.ntw;
-  const int g_t = kk / d.Cp_in, g_c = kk - g_t * d.Cp_in;
+  const int g_t = kk / Cpi, g_c = kk - g_t * Cpi;
   const bool gvalid = g_t < T_taps;
   const int ta = g_t / d.ntw, tb = g_t - ta * d.ntw;
   const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
   // per-piece pixel coordinates, advanced incrementally (no division in the loop)
-  int pn[PPT], ph[PPT], pw[PPT];
-  long pp[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; ++i) {
-    const long p = (long)s_begin * BKP + rb + RSTEP * i;
-    pp[i] = p;
-    const long nn = p / npix;
-    const int rem = (int)(p - nn * npix);
-    pn[i] = (int)nn; ph[i] = rem / d.Wg; pw[i] = rem - ph[i] * d.Wg;
+  int pn0, pn1, pn2, pn3, ph0, ph1, ph2, ph3, pw0, pw1, pw2, pw3;
+  long pbase = (long)s_begin * BKP + rb;
+  {
+    auto split = [&](long p, int& n_, int& h_, int& w_) {
+      const long nn = p / npix;
+      const int rem = (int)(p - nn * npix);
+      n_ = (int)nn; h_ = rem / Wg; w_ = rem - h_ * Wg;
+    };
+    split(pbase, pn0, ph0, pw0);
+    split(pbase + RSTEP, pn1, ph1, pw1);
+    split(pbase + 2 * RSTEP, pn2, ph2, pw2);
+    split(pbase + 3 * RSTEP, pn3, ph3, pw3);
+  }
+  static_assert(PPT == 4, "four pieces per thread");
+
+#define P2PHD_WG_PIECE(I, PN, PH, PW)                                                                        \
+  {                                                                                                          \
+    const T* s1 = zero;                                                                                      \
+    const T* s2 = zero;                                                                                      \
+    const long pp = pbase + (I) * RSTEP;                                                                     \
+    if (pp < P) {                                                                                            \
+      if (mvalid) s1 = rows + (size_t)pp * Cp_r + mcol;                                                      \
+      if (gvalid) {                                                                                          \
+        int hi = PH * sh + dh, wi = PW * sw + dw;                                                            \
+        if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }                         \
+        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) s2 = gat + ((size_t)(PN * Hin + hi) * Win + wi) * Cpi + g_c; \
+      }                                                                                                      \
+    }                                                                                                        \
+    __builtin_amdgcn_global_load_lds((gbl_ptr)s1, (lds_ptr)(A + (I) * RSTEP * ROWB), 16, 0, 0);             \
+    __builtin_amdgcn_global_load_lds((gbl_ptr)s2, (lds_ptr)(G + (I) * RSTEP * ROWB), 16, 0, 0);             \
+    PW += BKP;                                                                                               \
+    while (PW >= Wg) { PW -= Wg; ++PH; }                                                                     \
+    while (PH >= Hg) { PH -= Hg; ++PN; }                                                                     \
   }
 
-  uint4 ra[PPT], rg[PPT];
-  auto issue_loads = [&]() {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const T* s1 = zero;
-      const T* s2 = zero;
-      if (pp[i] < P) {
-        if (mvalid) s1 = rows + (size_t)pp[i] * Cp_r + mcol;
-        if (gvalid) {
-          int hi = ph[i] * d.sh + dh, wi = pw[i] * d.sw + dw;
-          if (d.pad_mode == 1) { hi = reflect_idx(hi, d.Hin); wi = reflect_idx(wi, d.Win); }
-          if (hi >= 0 && hi < d.Hin && wi >= 0 && wi < d.Win)
-            s2 = gat + ((size_t)(pn[i] * d.Hin + hi) * d.Win + wi) * d.Cp_in + g_c;
-        }
-      }
-      ra[i] = *reinterpret_cast<const uint4*>(s1);
-      rg[i] = *reinterpret_cast<const uint4*>(s2);
-      pp[i] += BKP;
-      pw[i] += BKP;
-      while (pw[i] >= d.Wg) { pw[i] -= d.Wg; ++ph[i]; }
-      while (ph[i] >= d.Hg) { ph[i] -= d.Hg; ++pn[i]; }
-    }
-  };
-  auto write_lds = [&](int stage) {
-    char* A = smem + stage * 2 * TILE;
+  auto issue = [&](int stage) {
+    char* A = smem + stage * 2 * TILE + (RPW * wave) * ROWB;
     char* G = A + TILE;
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int row = rb + RSTEP * i;
-      *reinterpret_cast<uint4*>(A + row * ROWB + chunk * 16) = ra[i];
-      *reinterpret_cast<uint4*>(G + row * ROWB + chunk * 16) = rg[i];
-    }
+    P2PHD_WG_PIECE(0, pn0, ph0, pw0)
+    P2PHD_WG_PIECE(1, pn1, ph1, pw1)
+    P2PHD_WG_PIECE(2, pn2, ph2, pw2)
+    P2PHD_WG_PIECE(3, pn3, ph3, pw3)
+    pbase += BKP;
   };
+#undef P2PHD_WG_PIECE
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -355,17 +381,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict
     const char* A = smem + stage * 2 * TILE;
     const char* G = A + TILE;
     if constexpr (sizeof(T) == 2) {
-      // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i
+      // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i.
+      // lane 4q+p of the group supplies row (8h + q), logical 8-byte column unit u = 4*(g&1) + p  (u>>1 = 16-B chunk)
       const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3, h = g >> 1;
-      const int colo = (16 * (g & 1) + 4 * pq) * 2;
+      const int u = 4 * (g & 1) + pq;
+      const int swz = q << 2;                                // (row & 3) << 2 with row = 16 sub + 8 h + q (+4)
 #pragma unroll
       for (int sub = 0; sub < BKP / 16; ++sub) {
         const int prow = 16 * sub + 8 * h + q;
         bf16x8 af[2], gf[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const char* pa = A + prow * ROWB + (wm * 64 + i * 32) * 2 + colo;
-          const char* pg = G + prow * ROWB + (wn * 64 + i * 32) * 2 + colo;
+          const int ca = (wm * 64 + i * 32) / 8 + (u >> 1);  // logical chunk
+          const int cg = (wn * 64 + i * 32) / 8 + (u >> 1);
+          const char* pa = A + prow * ROWB + ((ca ^ swz) << 4) + 8 * (u & 1);
+          const char* pg = G + prow * ROWB + ((cg ^ swz) << 4) + 8 * (u & 1);
           const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
           const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
           const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pg));
@@ -400,14 +430,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict
     }
   };
 
-  issue_loads();
-  write_lds(0);
+  issue(0);
   __syncthreads();
   int st = 0;
   for (int s = s_begin; s < s_end; ++s) {
-    if (s + 1 < s_end) issue_loads();
+    if (s + 1 < s_end) issue(st ^ 1);
     compute(st);
-    if (s + 1 < s_end) write_lds(st ^ 1);
     __syncthreads();
     st ^= 1;
   }
@@ -418,11 +446,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(GDesc d, const T* __restrict
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int col = j0 + wn * 64 + j * 32 + lr;
-      if (col >= d.KK) continue;
+      if (col >= KK) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float* dst = dwp + (size_t)row * d.KK + col;
+        float* dst = dwp + (size_t)row * KK + col;
         if (use_atomic) atomicAdd(dst, acc[i][j][e]);
         else *dst = acc[i][j][e];
       }
@@ -511,27 +539,38 @@ __global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restri
   }
 }
 
-// column sums of a [P][Cp] matrix (bias gradient); db must be zeroed beforehand
+// column sums of a [P][Cp] matrix (bias gradient); db must be zeroed beforehand.
+// Block = cpg channel pieces x R pixel rows; partial sums meet in LDS so each block issues one atomic per channel.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ x, long P, int Cp, int K, float* __restrict__ db) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long P, int Cp, int K, float* __restrict__ db, int cpg) {
   constexpr int EPP = Elem<T>::EPP;
+  __shared__ float red[256 * 8];
   const int cpr = Cp / EPP;
-  const int pc = threadIdx.x % cpr;            // blockDim.x is a multiple of cpr (host guarantees)
-  const int rl = threadIdx.x / cpr;
-  const int rows_per_block = blockDim.x / cpr;
+  const int pl = threadIdx.x % cpg, rl = threadIdx.x / cpg, R = 256 / cpg;
+  const int pc = blockIdx.y * cpg + pl;
   float acc[EPP];
 #pragma unroll
   for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
-  for (long p = (long)blockIdx.x * rows_per_block + rl; p < P; p += (long)gridDim.x * rows_per_block) {
-    const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)p * Cp + pc * EPP);
-    const T* vv = reinterpret_cast<const T*>(&v);
+  if (pc < cpr) {
+    for (long p = (long)blockIdx.x * R + rl; p < P; p += (long)gridDim.x * R) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)p * Cp + pc * EPP);
+      const T* vv = reinterpret_cast<const T*>(&v);
 #pragma unroll
-    for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+      for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+    }
   }
 #pragma unroll
-  for (int k = 0; k < EPP; ++k) {
-    const int c = pc * EPP + k;
-    if (c < K) atomicAdd(&db[c], acc[k]);
+  for (int k = 0; k < EPP; ++k) red[threadIdx.x * 8 + k] = acc[k];
+  __syncthreads();
+  if (rl == 0 && pc < cpr) {
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = pc * EPP + k;
+      if (c >= K) continue;
+      float t = 0.f;
+      for (int r = 0; r < R; ++r) t += red[(r * cpg + pl) * 8 + k];
+      atomicAdd(&db[c], t);
+    }
   }
 }
 
@@ -558,12 +597,10 @@ int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float
 template <typename T>
 int launch_gconv_t(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
                    float* stats, hipStream_t st) {
-  // pick the N tile that wastes the fewest MFMA columns
+  // N tile: the 128-wide tile has the best MFMA density (64x64 per wave) and reads the gathered A operand once;
+  // narrower tiles only for layers that would leave most of it empty
   const int k = d.Cp_out;
-  auto waste = [&](int bn) { return ((k + bn - 1) / bn) * bn - k; };
-  int bn = 128;
-  if (waste(64) < waste(bn)) bn = 64;
-  if (waste(32) < waste(bn)) bn = 32;
+  const int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
   if (bn == 128) return launch_gconv_cfg<T, 128, 2, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
   if (bn == 64) return launch_gconv_cfg<T, 64, 2, 2, 2, 1>(d, in, wp, bias, addend, out, stats, st);
   return launch_gconv_cfg<T, 32, 4, 1, 1, 1>(d, in, wp, bias, addend, out, stats, st);
@@ -604,7 +641,7 @@ int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_ro
   if (use_atomic) (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
   dim3 grid((unsigned)((d.KK + 127) / 128), (unsigned)(M_rows_pad / 128), (unsigned)splits);
   if (dtype == P2PHD_BF16) {
-    constexpr int lds = 2 * 2 * 64 * (128 * 2 + 64);
+    constexpr int lds = 2 * 2 * 64 * (128 * 2);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, d, (const bf16_t*)rows, (const bf16_t*)gat, dwp, Cp_r, sps, use_atomic);
   } else if (dtype == P2PHD_F32) {
@@ -654,15 +691,16 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hi
   if (P == 0) return P2PHD_OK;
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   const int cpr = Cp / epp;
-  P2PHD_REQUIRE(cpr <= 1024, "colsum: too many channels");
-  int threads = (256 / cpr) * cpr;
-  if (threads == 0) threads = cpr;
-  const int rpb = threads / cpr;
-  const int blocks = (int)std::min<long>((P + rpb * 8 - 1) / (rpb * 8), 2048);
+  int cpg = 1;
+  while (cpg * 2 <= cpr && cpg * 2 <= 64) cpg *= 2;
+  const int R = 256 / cpg;
+  const int ygroups = (cpr + cpg - 1) / cpg;
+  const int xblocks = (int)std::max<long>(1, std::min<long>((P + R * 32 - 1) / (R * 32), 512));
+  dim3 grid(xblocks, ygroups);
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(blocks), dim3(threads), 0, st, (const bf16_t*)x, P, Cp, K, db);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, P, Cp, K, db, cpg);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, dim3(blocks), dim3(threads), 0, st, (const float*)x, P, Cp, K, db);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, P, Cp, K, db, cpg);
   return check_launch("colsum");
 }
 
