@@ -56,7 +56,7 @@ def time_trunk_conv(batch, iters=20):
     stats = torch.zeros(batch, 768, 2, device="cuda")
     L = _ops.lib()
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
-                                               _ops.stream_ptr()))
+                                               None, _ops.stream_ptr()))
     for _ in range(3):
         call()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

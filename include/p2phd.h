@@ -107,8 +107,9 @@ int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w,
 
 /* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], zeroed by the caller) the per-(n,channel)
  * sum and sum of squares of conv(x)+bias are accumulated into it (what InstanceNorm2d needs, networks.py:22). */
+size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c);   /* non-zero only for <= 4-channel layers */
 int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_fwd, const float* bias, int act,
-                   void* y, float* stats, void* stream);
+                   void* y, float* stats, void* workspace, void* stream);
 
 /* dx = conv^T(dy) (+ addend, same layout as dx).  Replaces autograd of F.conv2d / F.conv_transpose2d and, for
  * pad_mode = 1, of ReflectionPad2d as well (needs p2phd_conv_dgrad_workspace_bytes of scratch). */

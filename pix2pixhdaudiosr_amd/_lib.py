@@ -29,7 +29,8 @@ SIGNATURES = {
     "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
-    "p2phd_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
+    "p2phd_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "p2phd_conv_dgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_workspace_bytes": (C.c_size_t, [_vp]),

@@ -192,7 +192,9 @@ class ConvBlockFn(torch.autograd.Function):
         y = torch.empty((N, Ho, Wo, Cp_out), dtype=x.dtype, device=x.device)
         stats = torch.zeros((N, Cp_out, 2), dtype=torch.float32, device=x.device) if spec.norm else None
         fused_act = ACT_NONE if spec.norm else spec.act
-        check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), stream_ptr()), "conv_fwd")
+        wsb = L.p2phd_conv_fwd_workspace_bytes(C.byref(d))
+        ws = workspace(wsb, x.device) if wsb else None
+        check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
         if spec.norm:
             res = None if residual is None else phys(residual, "residual")
             out = torch.empty_like(y)

@@ -272,18 +272,30 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
 //   rows   : [N*Hg*Wg][Cp_r]   the tensor on the pixel grid (dy for Conv2d, x for ConvTranspose2d)
 //   gather : [N,Hin,Win,Cp_in] the tensor reached through the taps
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int TM>
 __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
                                                     float* __restrict__ dwp, int Cp_r, int steps_per_split, int use_atomic) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int BKP = sizeof(T) == 2 ? 64 : 32;             // pixels per K-step
-  constexpr int TM = 128, TN = 128;
-  constexpr int ROWB = TM * (int)sizeof(T);                 // 256 B (bf16) / 512 B (f32) LDS rows, unpadded
+  constexpr int TN = 128;
+  static_assert(TM == 128 || TM == 32, "row tile");
+  constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+  constexpr int MI = TM / WAVES_M / 32, NI = TN / WAVES_N / 32;
+  // gather-operand tile [BKP][TN]
+  constexpr int ROWB = TN * (int)sizeof(T);                 // 256 B (bf16) / 512 B (f32) LDS rows, unpadded
   constexpr int TILE = BKP * ROWB;
-  constexpr int CPR = TM / EPP;                             // 16-byte pieces per row: 16 / 32
+  constexpr int CPR = TN / EPP;                             // 16-byte pieces per row: 16 / 32
   constexpr int PPT = BKP * CPR / 256;                      // pieces per thread per tile (4)
   constexpr int RSTEP = 256 / CPR;                          // row distance between a thread's pieces
   constexpr int RPW = 64 / CPR;                             // rows one wave instruction fills: 4 / 2
+  // rows-operand tile [BKP][TM]
+  constexpr int ROWA = TM * (int)sizeof(T);
+  constexpr int TILEA = BKP * ROWA;
+  constexpr int CPRA = TM / EPP;
+  constexpr int PPTA = BKP * CPRA / 256;                    // 4 (TM 128) or 1 (TM 32)
+  constexpr int RSTEPA = 256 / CPRA;
+  constexpr int RPWA = 64 / CPRA;
+  constexpr int STAGE = TILE + TILEA;
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int j0 = blockIdx.x * TN;                           // first kk column
   const int m0 = blockIdx.y * TM;                           // first output row
   const int npix = Hg * Wg;
@@ -311,7 +323,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
   const int slot = tid % CPR;
   const int chunk = sizeof(T) == 2 ? (slot ^ ((rb & 3) << 2)) : slot;
   const T* zero = reinterpret_cast<const T*>(g_zero_page);
-  const int mcol = m0 + chunk * EPP;                        // rows-operand column, fixed per thread
+  const int rbA = tid / CPRA, slotA = tid % CPRA;
+  const int chunkA = (sizeof(T) == 2 && TM == 128) ? (slotA ^ ((rbA & 3) << 2)) : slotA;
+  const int mcol = m0 + chunkA * EPP;                       // rows-operand column, fixed per thread
   const bool mvalid = mcol < Cp_r;
   const int kk = j0 + chunk * EPP;                          // gather-operand (tap, channel), fixed per thread
   const int T_taps = d.nth * d.ntw;
@@ -340,27 +354,32 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 
 #define P2PHD_WG_PIECE(I, PN, PH, PW)                                                                        \
   {                                                                                                          \
-    const T* s1 = zero;                                                                                      \
     const T* s2 = zero;                                                                                      \
     const long pp = pbase + (I) * RSTEP;                                                                     \
     if (pp < P) {                                                                                            \
-      if (mvalid) s1 = rows + (size_t)pp * Cp_r + mcol;                                                      \
       if (gvalid) {                                                                                          \
         int hi = PH * sh + dh, wi = PW * sw + dw;                                                            \
         if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }                         \
         if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) s2 = gat + ((size_t)(PN * Hin + hi) * Win + wi) * Cpi + g_c; \
       }                                                                                                      \
     }                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gbl_ptr)s1, (lds_ptr)(A + (I) * RSTEP * ROWB), 16, 0, 0);             \
     __builtin_amdgcn_global_load_lds((gbl_ptr)s2, (lds_ptr)(G + (I) * RSTEP * ROWB), 16, 0, 0);             \
     PW += BKP;                                                                                               \
     while (PW >= Wg) { PW -= Wg; ++PH; }                                                                     \
     while (PH >= Hg) { PH -= Hg; ++PN; }                                                                     \
   }
 
+  long pstep = (long)s_begin * BKP;
   auto issue = [&](int stage) {
-    char* A = smem + stage * 2 * TILE + (RPW * wave) * ROWB;
-    char* G = A + TILE;
+    char* A = smem + stage * STAGE + (RPWA * wave) * ROWA;
+    char* G = smem + stage * STAGE + TILEA + (RPW * wave) * ROWB;
+#pragma unroll
+    for (int i = 0; i < PPTA; ++i) {
+      const long pa = pstep + rbA + RSTEPA * i;
+      const T* s1 = (mvalid && pa < P) ? rows + (size_t)pa * Cp_r + mcol : zero;
+      __builtin_amdgcn_global_load_lds((gbl_ptr)s1, (lds_ptr)(A + i * RSTEPA * ROWA), 16, 0, 0);
+    }
+    pstep += BKP;
     P2PHD_WG_PIECE(0, pn0, ph0, pw0)
     P2PHD_WG_PIECE(1, pn1, ph1, pw1)
     P2PHD_WG_PIECE(2, pn2, ph2, pw2)
@@ -369,45 +388,49 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
   };
 #undef P2PHD_WG_PIECE
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   auto compute = [&](int stage) {
-    const char* A = smem + stage * 2 * TILE;
-    const char* G = A + TILE;
+    const char* A = smem + stage * STAGE;
+    const char* G = A + TILEA;
     if constexpr (sizeof(T) == 2) {
       // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i.
       // lane 4q+p of the group supplies row (8h + q), logical 8-byte column unit u = 4*(g&1) + p  (u>>1 = 16-B chunk)
       const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3, h = g >> 1;
       const int u = 4 * (g & 1) + pq;
       const int swz = q << 2;                                // (row & 3) << 2 with row = 16 sub + 8 h + q (+4)
+      const int swzA = TM == 128 ? swz : 0;
+      typedef __attribute__((address_space(3))) s16x4* trp;
 #pragma unroll
       for (int sub = 0; sub < BKP / 16; ++sub) {
         const int prow = 16 * sub + 8 * h + q;
-        bf16x8 af[2], gf[2];
+        bf16x8 af[MI], gf[NI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int ca = (wm * 64 + i * 32) / 8 + (u >> 1);  // logical chunk
-          const int cg = (wn * 64 + i * 32) / 8 + (u >> 1);
-          const char* pa = A + prow * ROWB + ((ca ^ swz) << 4) + 8 * (u & 1);
-          const char* pg = G + prow * ROWB + ((cg ^ swz) << 4) + 8 * (u & 1);
-          const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa));
-          const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pa + 4 * ROWB));
-          const s16x4 g0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pg));
-          const s16x4 g1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(pg + 4 * ROWB));
+        for (int i = 0; i < MI; ++i) {
+          const int ca = (wm * (MI * 32) + i * 32) / 8 + (u >> 1);  // logical chunk
+          const char* pa = A + prow * ROWA + ((ca ^ swzA) << 4) + 8 * (u & 1);
           s16x4* ad = reinterpret_cast<s16x4*>(&af[i]);
-          s16x4* gd = reinterpret_cast<s16x4*>(&gf[i]);
-          ad[0] = a0; ad[1] = a1; gd[0] = g0; gd[1] = g1;
+          ad[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pa));
+          ad[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pa + 4 * ROWA));
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NI; ++j) {
+          const int cg = (wn * (NI * 32) + j * 32) / 8 + (u >> 1);
+          const char* pg = G + prow * ROWB + ((cg ^ swz) << 4) + 8 * (u & 1);
+          s16x4* gd = reinterpret_cast<s16x4*>(&gf[j]);
+          gd[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pg));
+          gd[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pg + 4 * ROWB));
+        }
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
       }
     } else {
@@ -415,16 +438,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 #pragma unroll 4
       for (int s2 = 0; s2 < BKP / 2; ++s2) {
         const int prow = 2 * s2 + lh;
-        float af[2], gf[2];
+        float af[MI], gf[NI];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          af[i] = *reinterpret_cast<const float*>(A + prow * ROWB + (wm * 64 + i * 32 + lr) * 4);
-          gf[i] = *reinterpret_cast<const float*>(G + prow * ROWB + (wn * 64 + i * 32 + lr) * 4);
-        }
+        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float*>(A + prow * ROWA + (wm * (MI * 32) + i * 32 + lr) * 4);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NI; ++j) gf[j] = *reinterpret_cast<const float*>(G + prow * ROWB + (wn * (NI * 32) + j * 32 + lr) * 4);
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], gf[j], acc[i][j], 0, 0, 0);
       }
     }
@@ -442,14 +464,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int col = j0 + wn * 64 + j * 32 + lr;
+    for (int j = 0; j < NI; ++j) {
+      const int col = j0 + wn * (NI * 32) + j * 32 + lr;
       if (col >= KK) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const int row = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float* dst = dwp + (size_t)row * KK + col;
         if (use_atomic) atomicAdd(dst, acc[i][j][e]);
         else *dst = acc[i][j][e];
@@ -462,35 +484,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 // and the inverse for gradients (packed f32 -> master layout, overwrite)
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void pack_kernel(GDesc d, const float* __restrict__ w, T* __restrict__ wp, int rows, int rows_pad, int inner,
-                            long s_row, long s_inner, int S) {
+__global__ void pack_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp, int rows_pad) {
   const long total = (long)rows_pad * d.KK;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const int row = (int)(e / d.KK);
     const int kk = (int)(e - (long)row * d.KK);
     const int t = kk / d.Cp_in, c = kk - t * d.Cp_in;
     float v = 0.f;
-    if (row < rows && t < d.nth * d.ntw && c < inner) {
+    if (row < m.rows && t < d.nth * d.ntw && c < m.inner) {
       const int ta = t / d.ntw, tb = t - ta * d.ntw;
       const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
-      v = w[row * s_row + c * s_inner + r * S + s];
+      v = w[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s];
     }
     wp[e] = from_f<T>(v);
   }
 }
 
-__global__ void unpack_grad_kernel(GDesc d, const float* __restrict__ dwp, float* __restrict__ dw, int rows, int inner,
-                                   long s_row, long s_inner, int S) {
+__global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp, float* __restrict__ dw) {
   const int T_taps = d.nth * d.ntw;
-  const long total = (long)rows * T_taps * inner;
+  const long total = (long)m.rows * T_taps * m.inner;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % inner);
-    const long r2 = e / inner;
+    const int c = (int)(e % m.inner);
+    const long r2 = e / m.inner;
     const int t = (int)(r2 % T_taps);
     const int row = (int)(r2 / T_taps);
     const int ta = t / d.ntw, tb = t - ta * d.ntw;
     const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
-    dw[row * s_row + c * s_inner + r * S + s] = dwp[(size_t)row * d.KK + t * d.Cp_in + c];
+    dw[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s] =
+        dwp[(size_t)row * d.KK + t * d.Cp_in + c];
   }
 }
 
@@ -621,13 +642,26 @@ int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, cons
   return P2PHD_EUNSUPPORTED;
 }
 
-int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows_pad, const void* gat, float* dwp,
-                 hipStream_t st) {
-  // dwp: [M_rows_pad][KK] f32, M_rows_pad a multiple of 128
+template <typename T, int TM>
+void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* dwp, int Cp_r, int M_rows_pad, int sps,
+                      int splits, int use_atomic, hipStream_t st) {
+  constexpr int bkp = sizeof(T) == 2 ? 64 : 32;
+  constexpr int lds = 2 * bkp * (128 + TM) * (int)sizeof(T);
+  auto kern = wgrad_kernel<T, TM>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  dim3 grid((unsigned)((d.KK + 127) / 128), (unsigned)(M_rows_pad / TM), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, use_atomic);
+}
+
+int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad, const void* gat,
+                 float* dwp, hipStream_t st) {
+  // dwp: [M_rows_pad][KK] f32, M_rows_pad a multiple of 128; M_rows = rows that carry data
   const long P = (long)d.N * d.Hg * d.Wg;
   const int bkp = dtype == P2PHD_BF16 ? 64 : 32;
   const int total_steps = (int)((P + bkp - 1) / bkp);
-  const int tiles = (M_rows_pad / 128) * ((d.KK + 127) / 128);
+  const int tm = M_rows <= 32 ? 32 : 128;                       // narrow row tile for folded 2-channel layers
+  const int mrows = tm == 32 ? 32 : M_rows_pad;
+  const int tiles = (mrows / tm) * ((d.KK + 127) / 128);
   if (total_steps == 0) {
     (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
     return P2PHD_OK;
@@ -638,16 +672,13 @@ int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_ro
   const int sps = (total_steps + splits - 1) / splits;
   splits = (total_steps + sps - 1) / sps;
   const int use_atomic = splits > 1;
-  if (use_atomic) (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
-  dim3 grid((unsigned)((d.KK + 127) / 128), (unsigned)(M_rows_pad / 128), (unsigned)splits);
+  if (use_atomic) (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)mrows * d.KK, st);
   if (dtype == P2PHD_BF16) {
-    constexpr int lds = 2 * 2 * 64 * (128 * 2);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, st, d, (const bf16_t*)rows, (const bf16_t*)gat, dwp, Cp_r, sps, use_atomic);
+    if (tm == 32) launch_wgrad_cfg<bf16_t, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
+    else launch_wgrad_cfg<bf16_t, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
   } else if (dtype == P2PHD_F32) {
-    constexpr int lds = 2 * 2 * 32 * (128 * 4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, st, d, (const float*)rows, (const float*)gat, dwp, Cp_r, sps, use_atomic);
+    if (tm == 32) launch_wgrad_cfg<float, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
+    else launch_wgrad_cfg<float, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
   } else {
     set_error("wgrad: unsupported dtype %d", dtype);
     return P2PHD_EUNSUPPORTED;
@@ -655,22 +686,20 @@ int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_ro
   return check_launch("wgrad");
 }
 
-int launch_pack(const GDesc& d, int dtype, const float* w, void* wp, int rows, int rows_pad, int inner, long s_row,
-                long s_inner, int S, hipStream_t st) {
+int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
   const long total = (long)rows_pad * d.KK;
   const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, d, w, (bf16_t*)wp, rows, rows_pad, inner, s_row, s_inner, S);
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
   else
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, d, w, (float*)wp, rows, rows_pad, inner, s_row, s_inner, S);
+    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, d, m, w, (float*)wp, rows_pad);
   return check_launch("pack_weights");
 }
 
-int launch_unpack_grad(const GDesc& d, const float* dwp, float* dw, int rows, int inner, long s_row, long s_inner, int S,
-                       hipStream_t st) {
-  const long total = (long)rows * d.nth * d.ntw * inner;
+int launch_unpack_grad(const GDesc& d, const WMap& m, const float* dwp, float* dw, hipStream_t st) {
+  const long total = (long)m.rows * d.nth * d.ntw * m.inner;
   const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, dwp, dw, rows, inner, s_row, s_inner, S);
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, m, dwp, dw);
   return check_launch("unpack_grad");
 }
 

@@ -1,5 +1,6 @@
 // C ABI of the convolution family: turns a reference-level layer description (Conv2d / ConvTranspose2d with
-// stride, padding and an optional ReflectionPad2d in front) into gather-convolution launches (conv.hip).
+// stride, padding and an optional ReflectionPad2d in front) into gather-convolution launches (conv.hip), using the
+// W-fold forms (wfold.hip) for layers with <= 4 input or output channels.
 #include "convplan.h"
 #include <vector>
 
@@ -12,7 +13,20 @@ struct Plan {
   int rows_pad;
 };
 
+enum { FOLD_NONE = 0, FOLD_IN = 1, FOLD_OUT = 2 };
+
 int elem_size(int dtype) { return dtype == P2PHD_BF16 ? 2 : 4; }
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+void out_size(const p2phd_conv_desc* c, int* Ho, int* Wo) {
+  if (c->transposed) {
+    *Ho = (c->H - 1) * c->stride - 2 * c->pad + c->R + c->opad;
+    *Wo = (c->W - 1) * c->stride - 2 * c->pad + c->S + c->opad;
+  } else {
+    *Ho = (c->H + 2 * c->pad - c->R) / c->stride + 1;
+    *Wo = (c->W + 2 * c->pad - c->S) / c->stride + 1;
+  }
+}
 
 int check_desc(const p2phd_conv_desc* c) {
   P2PHD_REQUIRE(c != nullptr, "conv: null descriptor");
@@ -25,27 +39,18 @@ int check_desc(const p2phd_conv_desc* c) {
     P2PHD_REQUIRE(c->pad < c->H && c->pad < c->W, "conv: reflect padding %d needs a larger image than %dx%d", c->pad, c->H, c->W);
   }
   if (c->transposed) P2PHD_REQUIRE(c->opad >= 0 && c->opad < c->stride, "conv: output_padding must be < stride");
+  else P2PHD_REQUIRE(c->H + 2 * c->pad >= c->R && c->W + 2 * c->pad >= c->S, "conv: kernel larger than padded input");
   int Ho, Wo;
-  if (c->transposed) {
-    Ho = (c->H - 1) * c->stride - 2 * c->pad + c->R + c->opad;
-    Wo = (c->W - 1) * c->stride - 2 * c->pad + c->S + c->opad;
-  } else {
-    Ho = (c->H + 2 * c->pad - c->R) / c->stride + 1;
-    Wo = (c->W + 2 * c->pad - c->S) / c->stride + 1;
-    P2PHD_REQUIRE(c->H + 2 * c->pad >= c->R && c->W + 2 * c->pad >= c->S, "conv: kernel larger than padded input");
-  }
+  out_size(c, &Ho, &Wo);
   P2PHD_REQUIRE(Ho >= 1 && Wo >= 1, "conv: empty output");
   return P2PHD_OK;
 }
 
-void out_size(const p2phd_conv_desc* c, int* Ho, int* Wo) {
-  if (c->transposed) {
-    *Ho = (c->H - 1) * c->stride - 2 * c->pad + c->R + c->opad;
-    *Wo = (c->W - 1) * c->stride - 2 * c->pad + c->S + c->opad;
-  } else {
-    *Ho = (c->H + 2 * c->pad - c->R) / c->stride + 1;
-    *Wo = (c->W + 2 * c->pad - c->S) / c->stride + 1;
-  }
+int fold_mode(const p2phd_conv_desc* c) {
+  if (c->transposed || c->stride != 1) return FOLD_NONE;
+  if (c->K <= 4 && c->S * c->K <= 32) return FOLD_OUT;
+  if (c->C <= 4 && c->S * c->C <= 32) return FOLD_IN;
+  return FOLD_NONE;
 }
 
 GDesc base_desc(int N) {
@@ -103,25 +108,84 @@ void transposed_plans(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
     }
 }
 
+// ---- W-fold plans (stride 1, not transposed) ----
+// output fold, forward: Y[n,ho,w',(tw,k)] on the grid Ho x Wy, Wy = Wo + S - 1
+Plan kfold_fwd_plan(const p2phd_conv_desc* c, int Ho, int Wo) {
+  Plan p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo + c->S - 1, c->S * c->K, c->R, 1, 1, c->pad, c->pad_mode);
+  return p;   // taps (th, -): dh = th - pad, dw = -pad
+}
+// output fold, input gradient: gathers dyE[n, i' + pe - th, j' + pe, (tw,k)]
+Plan kfold_dgrad_plan(const p2phd_conv_desc* c, int Ho, int Wo) {
+  const bool reflect = c->pad_mode == 1;
+  const int P = reflect ? c->pad : 0, pe = reflect ? 0 : c->pad;
+  Plan p{};
+  GDesc& d = p.d;
+  d = base_desc(c->N);
+  d.Hin = Ho; d.Win = Wo + c->S - 1; d.Cp_in = cpitch(c->S * c->K);
+  d.Hg = c->H + 2 * P; d.Wg = c->W + 2 * P; d.pad_mode = 0;
+  d.Hout = d.Hg; d.Wout = d.Wg; d.Cp_out = cpitch(c->C); d.Kout = c->C;
+  d.nth = c->R; d.ntw = 1; d.dh0 = pe; d.dh_step = -1; d.dw0 = pe;
+  d.KK = std::max(64, round_up(c->R * d.Cp_in, 64));
+  p.rows_pad = round_up(c->C, 128);
+  return p;
+}
+// input fold, forward: gathers Xe[n, ho + th - pad, wo, (tw,c)]
+Plan cfold_fwd_plan(const p2phd_conv_desc* c, int Ho, int Wo) {
+  Plan p = direct_plan(c->N, c->H, Wo, c->S * c->C, Ho, Wo, c->K, c->R, 1, 1, c->pad, c->pad_mode);
+  p.d.dw0 = 0;
+  return p;
+}
+
+WMap kfold_rows_map(const p2phd_conv_desc* c) {     // rows (tw,k), inner c
+  const long RS = (long)c->R * c->S;
+  return WMap{c->S * c->K, c->C, c->C * RS, RS, c->K, 1, c->C, 0, c->S};
+}
+WMap kfold_inner_map(const p2phd_conv_desc* c) {    // rows c, inner (tw,k)
+  const long RS = (long)c->R * c->S;
+  return WMap{c->C, c->S * c->K, RS, c->C * RS, c->C, 0, c->K, 1, c->S};
+}
+WMap cfold_map(const p2phd_conv_desc* c) {          // rows k, inner (tw,c)
+  const long RS = (long)c->R * c->S;
+  return WMap{c->K, c->S * c->C, c->C * RS, RS, c->K, 0, c->C, 1, c->S};
+}
+
 // which: 0 = forward, 1 = input gradient
-void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, int* rows, int* inner, long* s_row, long* s_inner) {
+void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, WMap* m) {
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   const long RS = (long)c->R * c->S;
-  if (which == 0 && !c->transposed) {
+  const int fold = fold_mode(c);
+  if (which == 0 && fold == FOLD_OUT) {
+    plans.push_back(kfold_fwd_plan(c, Ho, Wo)); *m = kfold_rows_map(c);
+  } else if (which == 0 && fold == FOLD_IN) {
+    plans.push_back(cfold_fwd_plan(c, Ho, Wo)); *m = cfold_map(c);
+  } else if (which == 1 && fold == FOLD_OUT) {
+    plans.push_back(kfold_dgrad_plan(c, Ho, Wo)); *m = kfold_inner_map(c);
+  } else if (which == 0 && !c->transposed) {
     plans.push_back(direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode));
-    *rows = c->K; *inner = c->C; *s_row = c->C * RS; *s_inner = RS;
+    *m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
   } else if (which == 0 && c->transposed) {
     transposed_plans(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, plans);
-    *rows = c->K; *inner = c->C; *s_row = RS; *s_inner = c->K * RS;          // weight [C][K][R][S]
+    *m = plain_map(c->K, c->C, RS, c->K * RS, c->S);                          // weight [C][K][R][S]
   } else if (which == 1 && !c->transposed) {
     const int P = c->pad_mode == 1 ? c->pad : 0;                               // reflect: gradient on the padded grid
     transposed_plans(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->stride, c->pad_mode == 1 ? 0 : c->pad, plans);
-    *rows = c->C; *inner = c->K; *s_row = RS; *s_inner = c->C * RS;          // weight [K][C][R][S]
+    *m = plain_map(c->C, c->K, RS, c->C * RS, c->S);                          // weight [K][C][R][S]
   } else {
     plans.push_back(direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0));
-    *rows = c->C; *inner = c->K; *s_row = c->K * RS; *s_inner = RS;          // weight [C][K][R][S]
+    *m = plain_map(c->C, c->K, c->K * RS, RS, c->S);                          // weight [C][K][R][S]
   }
+}
+
+size_t padded_dx_bytes(const p2phd_conv_desc* c) {
+  if (c->pad_mode != 1) return 0;
+  return align256((size_t)c->N * (c->H + 2 * c->pad) * (c->W + 2 * c->pad) * cpitch(c->C) * elem_size(c->dtype));
+}
+size_t folded_dy_bytes(const p2phd_conv_desc* c, int Ho, int Wo) {
+  return align256((size_t)c->N * Ho * (Wo + c->S - 1) * cpitch(c->S * c->K) * elem_size(c->dtype));
+}
+size_t folded_x_bytes(const p2phd_conv_desc* c, int Wo) {
+  return align256((size_t)c->N * c->H * Wo * cpitch(c->S * c->C) * elem_size(c->dtype));
 }
 
 }  // namespace
@@ -136,8 +200,8 @@ extern "C" int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo) {
 
 extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   if (check_desc(c) != P2PHD_OK || (which != 0 && which != 1)) return 0;
-  std::vector<Plan> plans; int rows, inner; long sr, si;
-  make_plans(c, which, plans, &rows, &inner, &sr, &si);
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, which, plans, &m);
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
   return n * elem_size(c->dtype);
@@ -147,35 +211,64 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(which == 0 || which == 1, "pack_weights: which must be 0 (forward) or 1 (input gradient)");
   P2PHD_REQUIRE(w && packed, "pack_weights: null pointer");
-  std::vector<Plan> plans; int rows, inner; long sr, si;
-  make_plans(c, which, plans, &rows, &inner, &sr, &si);
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, which, plans, &m);
   for (auto& p : plans) {
     char* dst = static_cast<char*>(packed) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_pack(p.d, c->dtype, w, dst, rows, p.rows_pad, inner, sr, si, c->S, (hipStream_t)stream)) return rc;
+    if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
   }
   return P2PHD_OK;
 }
 
+extern "C" size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c) {
+  if (check_desc(c) != P2PHD_OK) return 0;
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const int fold = fold_mode(c);
+  if (fold == FOLD_OUT) return folded_dy_bytes(c, Ho, Wo);      // Y has the shape of the folded dy
+  if (fold == FOLD_IN) return folded_x_bytes(c, Wo);
+  return 0;
+}
+
 extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* wp, const float* bias, int act,
-                              void* y, float* stats, void* stream) {
+                              void* y, float* stats, void* workspace, void* stream) {
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(act >= P2PHD_ACT_NONE && act <= P2PHD_ACT_RELU, "conv_fwd: bad activation %d", act);
   if (c->N == 0) return P2PHD_OK;
   P2PHD_REQUIRE(x && wp && y, "conv_fwd: null pointer");
-  std::vector<Plan> plans; int rows, inner; long sr, si;
-  make_plans(c, 0, plans, &rows, &inner, &sr, &si);
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, 0, plans, &m);
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const int fold = fold_mode(c);
+  P2PHD_REQUIRE(fold == FOLD_NONE || workspace, "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch");
+  if (fold == FOLD_OUT) {
+    Plan& p = plans[0];
+    if (int rc = launch_gconv(p.d, c->dtype, x, wp, nullptr, nullptr, workspace, nullptr, st)) return rc;
+    return launch_hsum(c->dtype, workspace, bias, y, stats, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, act, st);
+  }
+  if (fold == FOLD_IN) {
+    if (int rc = launch_expand_in(c->dtype, x, workspace, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
+    Plan& p = plans[0];
+    p.d.act = act;
+    return launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, stats, st);
+  }
   for (auto& p : plans) {
     p.d.act = act;
     const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, stats, (hipStream_t)stream)) return rc;
+    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, stats, st)) return rc;
   }
   return P2PHD_OK;
 }
 
 extern "C" size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
-  if (c->pad_mode != 1) return 0;
-  return (size_t)c->N * (c->H + 2 * c->pad) * (c->W + 2 * c->pad) * p2phd::cpitch(c->C) * elem_size(c->dtype);
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  size_t n = padded_dx_bytes(c);
+  if (fold_mode(c) == FOLD_OUT) n += folded_dy_bytes(c, Ho, Wo);
+  return n;
 }
 
 extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wp, const void* addend, void* dx,
@@ -183,26 +276,44 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
   if (int rc = check_desc(c)) return rc;
   if (c->N == 0) return P2PHD_OK;
   P2PHD_REQUIRE(dy && wp && dx, "conv_dgrad: null pointer");
-  std::vector<Plan> plans; int rows, inner; long sr, si;
-  make_plans(c, 1, plans, &rows, &inner, &sr, &si);
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, 1, plans, &m);
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
   const bool reflect = c->pad_mode == 1;
-  P2PHD_REQUIRE(!reflect || workspace, "conv_dgrad: reflect padding needs the workspace");
+  const bool kfold = fold_mode(c) == FOLD_OUT;
+  P2PHD_REQUIRE(!(reflect || kfold) || workspace, "conv_dgrad: this layer needs p2phd_conv_dgrad_workspace_bytes of scratch");
+  char* ws = static_cast<char*>(workspace);
+  void* dxp = ws;                                   // padded-grid gradient (reflect only)
+  const void* src = dy;
+  if (kfold) {
+    void* dye = ws + padded_dx_bytes(c);
+    if (int rc = launch_expand_dy(c->dtype, dy, dye, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
+    src = dye;
+  }
   for (auto& p : plans) {
     const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_gconv(p.d, c->dtype, dy, w, nullptr, reflect ? nullptr : addend, reflect ? workspace : dx, nullptr,
-                              (hipStream_t)stream)) return rc;
+    if (int rc = launch_gconv(p.d, c->dtype, src, w, nullptr, reflect ? nullptr : addend, reflect ? dxp : dx, nullptr, st)) return rc;
   }
-  if (reflect)
-    return launch_reflect_fold(c->dtype, workspace, addend, dx, c->N, c->H, c->W, p2phd::cpitch(c->C), c->pad, (hipStream_t)stream);
+  if (reflect) return launch_reflect_fold(c->dtype, dxp, addend, dx, c->N, c->H, c->W, cpitch(c->C), c->pad, st);
   return P2PHD_OK;
 }
 
 extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
-  const int M = c->transposed ? c->C : c->K;
-  const int inner = c->transposed ? c->K : c->C;
-  const int KK = std::max(64, p2phd::round_up(c->R * c->S * p2phd::cpitch(inner), 64));
-  return (size_t)p2phd::round_up(M, 128) * KK * sizeof(float);
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const int fold = fold_mode(c);
+  int M, KK;
+  size_t extra = 0;
+  if (fold == FOLD_OUT) { M = c->S * c->K; KK = std::max(64, round_up(c->R * cpitch(c->C), 64)); extra = folded_dy_bytes(c, Ho, Wo); }
+  else if (fold == FOLD_IN) { M = c->K; KK = std::max(64, round_up(c->R * cpitch(c->S * c->C), 64)); extra = folded_x_bytes(c, Wo); }
+  else {
+    M = c->transposed ? c->C : c->K;
+    KK = std::max(64, round_up(c->R * c->S * cpitch(c->transposed ? c->K : c->C), 64));
+  }
+  return align256((size_t)round_up(M, 128) * KK * sizeof(float)) + extra;
 }
 
 extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
@@ -213,22 +324,39 @@ extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const v
   out_size(c, &Ho, &Wo);
   const long RS = (long)c->R * c->S;
   hipStream_t st = (hipStream_t)stream;
+  const int fold = fold_mode(c);
   Plan p;
-  int rows, inner; long sr, si;
+  WMap m;
   const void *rows_t, *gat_t;
-  int Cp_r;
-  if (!c->transposed) {   // dW[k][c][r][s] = sum dy[n,ho,wo,k] * x[n, ho*s-pad+r, wo*s-pad+s', c]
-    p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
-    rows = c->K; inner = c->C; sr = c->C * RS; si = RS;
-    rows_t = dy; gat_t = x; Cp_r = p2phd::cpitch(c->K);
-  } else {                // dW[ci][co][r][s] = sum x[n,i,j,ci] * dy[n, i*s-pad+r, j*s-pad+s', co]
-    p = direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0);
-    rows = c->C; inner = c->K; sr = c->K * RS; si = RS;
-    rows_t = x; gat_t = dy; Cp_r = p2phd::cpitch(c->C);
-  }
+  int Cp_r, M;
   float* dwp = static_cast<float*>(workspace);
-  if (int rc = launch_wgrad(p.d, c->dtype, rows_t, Cp_r, p2phd::round_up(rows, 128), gat_t, dwp, st)) return rc;
-  if (int rc = launch_unpack_grad(p.d, dwp, dw, rows, inner, sr, si, c->S, st)) return rc;
-  if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, p2phd::cpitch(c->K), c->K, db, st);
+  if (fold == FOLD_OUT) {       // dWp[(tw,k)][th][c] = sum dyE[n,ho,w',(tw,k)] * x[n, ho+th-pad, w'-pad, c]
+    p = kfold_fwd_plan(c, Ho, Wo);
+    m = kfold_rows_map(c);
+    M = c->S * c->K;
+    char* dye = static_cast<char*>(workspace) + align256((size_t)round_up(M, 128) * p.d.KK * sizeof(float));
+    if (int rc = launch_expand_dy(c->dtype, dy, dye, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
+    rows_t = dye; gat_t = x; Cp_r = cpitch(M);
+  } else if (fold == FOLD_IN) { // dWp[k][th][(tw,c)] = sum dy[n,ho,wo,k] * Xe[n, ho+th-pad, wo, (tw,c)]
+    p = cfold_fwd_plan(c, Ho, Wo);
+    m = cfold_map(c);
+    M = c->K;
+    char* xe = static_cast<char*>(workspace) + align256((size_t)round_up(M, 128) * p.d.KK * sizeof(float));
+    if (int rc = launch_expand_in(c->dtype, x, xe, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
+    rows_t = dy; gat_t = xe; Cp_r = cpitch(c->K);
+  } else if (!c->transposed) {  // dW[k][c][r][s] = sum dy[n,ho,wo,k] * x[n, ho*s-pad+r, wo*s-pad+s', c]
+    p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
+    m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
+    M = c->K;
+    rows_t = dy; gat_t = x; Cp_r = cpitch(c->K);
+  } else {                      // dW[ci][co][r][s] = sum x[n,i,j,ci] * dy[n, i*s-pad+r, j*s-pad+s', co]
+    p = direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0);
+    m = plain_map(c->C, c->K, c->K * RS, RS, c->S);
+    M = c->C;
+    rows_t = x; gat_t = dy; Cp_r = cpitch(c->C);
+  }
+  if (int rc = launch_wgrad(p.d, c->dtype, rows_t, Cp_r, M, round_up(M, 128), gat_t, dwp, st)) return rc;
+  if (int rc = launch_unpack_grad(p.d, m, dwp, dw, st)) return rc;
+  if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, st);
   return P2PHD_OK;
 }

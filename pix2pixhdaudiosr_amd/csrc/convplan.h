@@ -16,19 +16,38 @@ struct GDesc {
   int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
 };
 
+// Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
+//   offset(row, c, r, s) = (row % row_mod) * s_row + (row / row_mod) * s_rowq
+//                        + (c % c_mod) * s_inner + (c / c_mod) * s_innerq + r * S + s
+// row_mod / c_mod split a folded index (horizontal tap, channel) when the W taps ride on the channel axis.
+struct WMap {
+  int rows, inner;
+  long s_row, s_inner;
+  int row_mod; long s_rowq;
+  int c_mod; long s_innerq;
+  int S;
+};
+inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
+  return WMap{rows, inner, s_row, s_inner, rows > 0 ? rows : 1, 0, inner > 0 ? inner : 1, 0, S};
+}
+
 inline int cpitch(int c) { return (c + 7) & ~7; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
                  void* out, float* stats, hipStream_t st);
-int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows_pad, const void* gat, float* dwp,
-                 hipStream_t st);
-int launch_pack(const GDesc& d, int dtype, const float* w, void* wp, int rows, int rows_pad, int inner, long s_row,
-                long s_inner, int S, hipStream_t st);
-int launch_unpack_grad(const GDesc& d, const float* dwp, float* dw, int rows, int inner, long s_row, long s_inner, int S,
-                       hipStream_t st);
+int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad, const void* gat,
+                 float* dwp, hipStream_t st);
+int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
+int launch_unpack_grad(const GDesc& d, const WMap& m, const float* dwp, float* dw, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st);
+
+int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,
+                     hipStream_t st);
+int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st);
+int launch_hsum(int dtype, const void* Y, const float* bias, void* y, float* stats, int N, int H, int Wo, int Wy, int K, int S,
+                int act, hipStream_t st);
 
 }  // namespace p2phd

@@ -1,0 +1,155 @@
+// W-fold helpers for the tiny-channel convolutions (the 2-channel 7x7 input / output layers of the generator,
+// networks.py:190,207, and the 1-channel 4x4 head of the discriminator, :361).
+//
+// An implicit GEMM whose channel dimension is 1-4 wastes most of every MFMA tile (channel pitch 8, N tile >= 32).
+// For those layers the horizontal kernel taps are folded into the channel axis, turning an R x S convolution into
+// an R x 1 one over S*C (input fold) or S*K (output fold) channels:
+//   input fold  : Xe[n,h,w,(tw,c)]   = x[n, h, w + tw - pad, c]          conv' = R x 1 over S*C channels
+//   output fold : Y [n,h,w',(tw,k)]  = sum_{th,c} x[n,h+th-pad,w'-pad,c] w[k,c,th,tw]   (one GEMM with N = S*K)
+//                 y [n,h,w,k]        = act(bias_k + sum_tw Y[n,h,w+tw,(tw,k)])            (hsum_kernel)
+//   and for the backward of an output-folded layer dyE[n,h,w',(tw,k)] = dy[n,h,w'-tw,k].
+// These three kernels are the cheap HBM-bound data movers around the GEMMs; tensors are NHWC with pitch 8.
+#include "convplan.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// Xe[n,h,wo,(tw*C + c)] = x[n,h,map(wo + tw - pad),c]   (map = reflect or zero), wo in [0,Wo)
+template <typename T>
+__global__ void expand_in_kernel(const T* __restrict__ x, T* __restrict__ xe, long NH, int W, int Wo, int C, int Cp, int S,
+                                 int pad, int pad_mode, int Cep) {
+  const long total = NH * Wo * Cep;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ce = (int)(e % Cep);
+    const long r = e / Cep;
+    const int wo = (int)(r % Wo);
+    const long nh = r / Wo;
+    float v = 0.f;
+    if (ce < S * C) {
+      const int tw = ce / C, c = ce - tw * C;
+      int wi = wo + tw - pad;
+      if (pad_mode == 1) wi = reflect_idx(wi, W);
+      if (wi >= 0 && wi < W) v = to_f(x[(nh * W + wi) * Cp + c]);
+    }
+    xe[e] = from_f<T>(v);
+  }
+}
+
+// dyE[n,h,w',(tw*K + k)] = dy[n,h,w'-tw,k] (zero outside [0,Wo)), w' in [0,Wy)
+template <typename T>
+__global__ void expand_dy_kernel(const T* __restrict__ dy, T* __restrict__ dye, long NH, int Wo, int Wy, int K, int Kp,
+                                 int S, int Cep) {
+  const long total = NH * Wy * Cep;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int ce = (int)(e % Cep);
+    const long r = e / Cep;
+    const int wy = (int)(r % Wy);
+    const long nh = r / Wy;
+    float v = 0.f;
+    if (ce < S * K) {
+      const int tw = ce / K, k = ce - tw * K;
+      const int w = wy - tw;
+      if (w >= 0 && w < Wo) v = to_f(dy[(nh * Wo + w) * Kp + k]);
+    }
+    dye[e] = from_f<T>(v);
+  }
+}
+
+// y[n,h,w,k] = act(bias_k + sum_tw Y[n,h,w+tw,(tw*K+k)]); optional InstanceNorm partial sums
+template <typename T>
+__global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, const float* __restrict__ bias, T* __restrict__ y,
+                                                   float* __restrict__ stats, int H, int Wo, int Wy, int K, int Kp, int S,
+                                                   int Cep, int act) {
+  // grid: (blocks over H*Wo pixels, N); thread -> one output pixel, all K (<= 4) channels
+  const int n = blockIdx.y;
+  const long HW = (long)H * Wo;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int w = (int)(p % Wo);
+    const long h = p / Wo;
+    const T* row = Y + (((size_t)n * H + h) * Wy + w) * Cep;
+    alignas(16) T outv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) outv[k] = from_f<T>(0.f);
+    for (int k = 0; k < K; ++k) {
+      float a = bias != nullptr ? bias[k] : 0.f;
+      for (int tw = 0; tw < S; ++tw) a += to_f(row[(size_t)tw * Cep + tw * K + k]);
+      s1[k] += a; s2[k] += a * a;
+      if (act == P2PHD_ACT_TANH) a = tanhf(a);
+      else if (act == P2PHD_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
+      else if (act == P2PHD_ACT_RELU) a = a > 0.f ? a : 0.f;
+      outv[k] = from_f<T>(a);
+    }
+    T* o = y + ((size_t)n * HW + p) * Kp;
+    if (sizeof(T) == 2) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(outv);
+    else { *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(outv); *reinterpret_cast<uint4*>(o + 4) = *reinterpret_cast<uint4*>(outv + 4); }
+  }
+  if (stats != nullptr) {
+    __shared__ float red[4][8];
+    for (int k = 0; k < K; ++k) {
+      float a = s1[k], b = s2[k];
+      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * k] = a; red[threadIdx.x >> 6][2 * k + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * K) {
+      const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+      atomicAdd(&stats[2 * ((size_t)n * Kp + (threadIdx.x >> 1)) + (threadIdx.x & 1)], t);
+    }
+  }
+}
+
+inline int grid_for(long work, int cap = 8192) { return (int)std::max<long>(1, std::min<long>((work + 255) / 256, cap)); }
+
+}  // namespace
+
+namespace p2phd {
+
+int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,
+                     hipStream_t st) {
+  const int Cp = cpitch(C), Cep = cpitch(S * C);
+  const long NH = (long)N * H;
+  const long total = NH * Wo * Cep;
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(expand_in_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)xe, NH, W, Wo, C, Cp, S, pad, pad_mode, Cep);
+  else
+    hipLaunchKernelGGL(expand_in_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, (float*)xe, NH, W, Wo, C, Cp, S, pad, pad_mode, Cep);
+  return check_launch("expand_in");
+}
+
+int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st) {
+  const int Kp = cpitch(K), Cep = cpitch(S * K);
+  const long NH = (long)N * Ho;
+  const long total = NH * Wy * Cep;
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(expand_dy_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dye, NH, Wo, Wy, K, Kp, S, Cep);
+  else
+    hipLaunchKernelGGL(expand_dy_kernel<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)dy, (float*)dye, NH, Wo, Wy, K, Kp, S, Cep);
+  return check_launch("expand_dy");
+}
+
+int launch_hsum(int dtype, const void* Y, const float* bias, void* y, float* stats, int N, int H, int Wo, int Wy, int K, int S,
+                int act, hipStream_t st) {
+  P2PHD_REQUIRE(K <= 4, "hsum: at most 4 output channels");
+  const int Kp = cpitch(K), Cep = cpitch(S * K);
+  dim3 grid(grid_for((long)H * Wo, 1024), N);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(hsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)Y, bias, (bf16_t*)y, stats, H, Wo, Wy, K, Kp, S, Cep, act);
+  else
+    hipLaunchKernelGGL(hsum_kernel<float>, grid, dim3(256), 0, st, (const float*)Y, bias, (float*)y, stats, H, Wo, Wy, K, Kp, S, Cep, act);
+  return check_launch("hsum");
+}
+
+}  // namespace p2phd
