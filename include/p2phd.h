@@ -39,6 +39,8 @@ const char* p2phd_last_error(void);
 int p2phd_abi_version(void);
 /* fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0 */
 int p2phd_device_info(char* name, int cap);
+/* tuning overrides for tests and A/B timing: "gconv_bm" = 0 (heuristic) | 128 | 256 */
+int p2phd_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------------------
  * MDCT4 / IMDCT4 (models/mdct.py:461-566).  n_fft a power of two in [16, 4096].

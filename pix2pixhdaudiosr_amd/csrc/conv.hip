@@ -39,7 +39,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__device__ uint4 g_zero_page[4];   // zero-initialised: source of every out-of-image / padding piece
 
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPP = 4; };    // elements per 16-byte piece
@@ -66,22 +65,25 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-constexpr int kBM = 128;
 constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
 
 // ------------------------------------------------------------------------------------------------------
 // gather convolution
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int BN, int WGM, int WGN, int MR, int NR>
-__global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
+template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
+__global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
                                                     const float* __restrict__ bias, const T* __restrict__ addend,
                                                     T* __restrict__ out, float* __restrict__ stats) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int BK = 8 * EPP;
-  constexpr int BM = kBM;
-  static_assert(WGM * WGN == 4 && WGM * MR * 32 == BM && WGN * NR * 32 == BN, "tile config");
+  constexpr int NT = BM * 2;                                  // threads: one wave per 64 x 64 (or narrower) sub-tile
+  constexpr int WGM = BM / (MR * 32), WGN = BN / (NR * 32);
+  static_assert(WGM * WGN * 64 == NT, "tile config");
   constexpr int STAGE = (BM + BN) * kRowBytes;
-  constexpr int NB = BN / 32;      // B pieces per thread per step
+  constexpr int RS = NT / 8;                                  // row distance between a thread's pieces
+  constexpr int NB = BN * 8 / NT;                             // B pieces per thread per step
+  static_assert(NB >= 1 && BM * 8 / NT == 4, "piece distribution");
+  constexpr int NLOADS = 4 + NB;                              // direct-to-LDS loads per thread per stage
 
   // descriptor fields used in loops live in registers (a by-value struct that is captured by reference ends
   // up in scratch memory)
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
   {  // gather table: input pixel index (or -1) per (tap, tile row)
     const int Hin = d.Hin, Win = d.Win, sh = d.sh, sw = d.sw, ntw = d.ntw, pad_mode = d.pad_mode;
     const int dh0 = d.dh0, dhs = d.dh_step, dw0 = d.dw0, dws = d.dw_step;
-    for (int e = tid; e < T_taps * BM; e += 256) {
+    for (int e = tid; e < T_taps * BM; e += NT) {
       const int t = e / BM, r = e - t * BM;
       const int p = p_base + r;
       int off = -1;
@@ -121,39 +123,61 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
   }
   __syncthreads();
 
-  // Direct global -> LDS staging (global_load_lds_dwordx4): one wave instruction fills 8 consecutive 128-byte
+  // Direct global -> LDS staging (buffer_load_dwordx4 ... lds): one wave instruction fills 8 consecutive 128-byte
   // tile rows linearly (lane l -> row l>>3, slot l&7).  The bank-conflict swizzle therefore sits on the SOURCE:
   // the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7), and fragment reads undo it.
-  const int rbase = tid >> 3;                                 // rows rbase + 32 i
+  // Buffer addressing keeps the per-piece address a 32-bit offset (one VALU add per piece and K step) and gives
+  // zero padding for free: an out-of-image piece uses an offset beyond num_records, which loads zeros.
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
+  constexpr int SZ = (int)sizeof(T);
+  const int rbase = tid >> 3;                                 // rows rbase + RS i
   const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);          // logical 16-byte chunk of the K slab
-  int a_t = (kchunk * EPP) / Cp, a_c = (kchunk * EPP) % Cp;
+  const int CpB = Cp * SZ;
+  int a_t = (kchunk * EPP) / Cp, a_cB = ((kchunk * EPP) % Cp) * SZ;
   int cur_t = -1;
-  int rowoff[4] = {-1, -1, -1, -1};
-  const T* bsrc = wp + (size_t)(n0 + rbase) * KK + kchunk * EPP;
-  const size_t brow = (size_t)32 * KK;
-  const T* zero = reinterpret_cast<const T*>(g_zero_page);
+  unsigned aoffb[4] = {kOOB, kOOB, kOOB, kOOB}, va[4];
+  unsigned boffb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) boffb[i] = (unsigned)(((size_t)(n0 + rbase + RS * i) * KK + kchunk * EPP) * SZ);
+  const unsigned tab_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) int*)tab;
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)in, 0, (int)d.in_bytes, 0x00020000);
+  const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)d.w_bytes, 0x00020000);
 
-  auto issue = [&](int stage) {
-    char* A = stages + stage * STAGE + (8 * wave) * kRowBytes;
-    char* B = A + BM * kRowBytes;
+  // byte offsets of this thread's four A pieces for the next K slab
+  auto prepare = [&]() {
     if (a_t != cur_t) {
       cur_t = a_t;
+      if (a_t < T_taps) {
+        // asm: a C++ LDS read here would make hipcc drain the LDS-DMA queue (see compute)
+        int ro[4];
+        const unsigned ta = tab_base + (unsigned)(a_t * BM + rbase) * 4u;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rowoff[i] = a_t < T_taps ? tab[a_t * BM + rbase + 32 * i] : -1;
+        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(ro[i]) : "v"(ta + (unsigned)(RS * i * 4)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoffb[i] = ro[i] >= 0 ? (unsigned)ro[i] * (unsigned)CpB : kOOB;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aoffb[i] = kOOB;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const T* src = rowoff[i] >= 0 ? in + (size_t)rowoff[i] * Cp + a_c : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)(A + 32 * i * kRowBytes), 16, 0, 0);
+    for (int i = 0; i < 4; ++i) va[i] = aoffb[i] == kOOB ? kOOB : aoffb[i] + (unsigned)a_cB;
+    a_cB += kRowBytes;
+    while (a_cB >= CpB) { a_cB -= CpB; ++a_t; }
+  };
+  // piece j of a tile: 0..3 = A rows rbase + RS j, 4.. = B rows; tile = K-slab index (scalar offset of B)
+  auto issue_piece = [&](int slot, int tile, int j) {
+    char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
+    if (j < 4) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(A + RS * j * kRowBytes), 16, (int)va[j], 0, 0, 0);
+    } else {
+      char* B = A + BM * kRowBytes;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(B + RS * (j - 4) * kRowBytes), 16, (int)boffb[j - 4],
+                                               tile * kRowBytes, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_ptr)(bsrc + i * brow), (lds_ptr)(B + 32 * i * kRowBytes), 16, 0, 0);
-    bsrc += BK;
-    a_c += BK;
-    while (a_c >= Cp) { a_c -= Cp; ++a_t; }
   };
 
   f32x16 acc[MR][NR];
@@ -165,56 +189,105 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int lr = lane & 31, lh = lane >> 5;
-  // fragment read offsets: row * 128 + ((jj ^ swz(row)) << 4) with jj = 2 ks + lh; swz(row) = (row >> 1) & 7
-  int aoff[MR], asw[MR], boff[NR], bsw[NR];
+  // Fragment reads are inline-asm ds_read_b128: hipcc cannot prove a C++ LDS read independent of the LDS-DMA still in
+  // flight and would drain it (s_waitcnt vmcnt(0)) in front of every K step; the waits here are counted by hand.
+  // byte offset inside a stage of the fragment of k-slab ks: row * 128 + (((2 ks + lh) ^ ((row >> 1) & 7)) << 4)
+  unsigned fa[MR][4], fb[NR][4];
+  {
+    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stages;
 #pragma unroll
-  for (int i = 0; i < MR; ++i) {
-    const int row = wm * (MR * 32) + i * 32 + lr;
-    aoff[i] = row * kRowBytes; asw[i] = (row >> 1) & 7;
-  }
+    for (int i = 0; i < MR; ++i) {
+      const int row = wm * (MR * 32) + i * 32 + lr;
 #pragma unroll
-  for (int j = 0; j < NR; ++j) {
-    const int row = wn * (NR * 32) + j * 32 + lr;
-    boff[j] = BM * kRowBytes + row * kRowBytes; bsw[j] = (row >> 1) & 7;
+      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = sbase + row * kRowBytes + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+      const int row = wn * (NR * 32) + j * 32 + lr;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        fb[j][ks] = sbase + BM * kRowBytes + row * kRowBytes + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4);
+    }
   }
 
-  auto compute = [&](int stage) {
-    const char* S = stages + stage * STAGE;
+  // One K slab (4 MFMA k-steps) from ring slot `slot`; when `pf` the NLOADS pieces of tile `pf_tile` are issued into
+  // ring slot `pf_slot` spread over the four k-steps, so each LDS-DMA issue hides behind an MFMA cluster.
+  auto compute = [&](int slot, bool pf, int pf_slot, int pf_tile) {
+    const unsigned so = (unsigned)(slot * STAGE);
+    uint4 af[2][MR], bfr[2][NR];
+    auto read_frags = [&](int ks, int buf) {
+#pragma unroll
+      for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"(fa[i][ks] + so));
+#pragma unroll
+      for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"(fb[j][ks] + so));
+    };
+    read_frags(0, 0);
+    if (pf) prepare();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int jj = 2 * ks + lh;
-      uint4 af[MR], bfr[NR];
+      const int buf = ks & 1;
+      if (pf) {
 #pragma unroll
-      for (int i = 0; i < MR; ++i) af[i] = *reinterpret_cast<const uint4*>(S + aoff[i] + ((jj ^ asw[i]) << 4));
-#pragma unroll
-      for (int j = 0; j < NR; ++j) bfr[j] = *reinterpret_cast<const uint4*>(S + boff[j] + ((jj ^ bsw[j]) << 4));
+        for (int j = ks; j < NLOADS; j += 4) issue_piece(pf_slot, pf_tile, j);
+      }
+      if (ks < 3) {
+        read_frags(ks + 1, buf ^ 1);
+        if constexpr (MR + NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else if constexpr (MR + NR == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
           if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[i]),
-                                                                *reinterpret_cast<bf16x8*>(&bfr[j]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
+                                                                *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);
           } else {
             // exact f32 MFMA; any k permutation is fine as long as A and B share it
-            const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[i]);
-            const f32x4 b4 = *reinterpret_cast<f32x4*>(&bfr[j]);
+            const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[buf][i]);
+            const f32x4 b4 = *reinterpret_cast<f32x4*>(&bfr[buf][j]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
           }
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
+  // NSTAGE-slot LDS ring, prefetch distance D = NSTAGE - 1.  The loads of tiles s+1 .. s+D-1 stay in flight ACROSS
+  // the barrier of tile s (counted vmcnt + raw s_barrier; __syncthreads() would drain them).  Tile s+D is issued
+  // into the slot tile s-1 was read from, which every wave has left once it is past this barrier.
   const int nsteps = KK / BK;
-  issue(0);
-  __syncthreads();                       // emits s_waitcnt vmcnt(0): the LDS-DMA of stage 0 has landed
-  for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) issue((s + 1) & 1);
-    compute(s & 1);
-    __syncthreads();
+  constexpr int D = NSTAGE - 1;
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    if (t < nsteps) {
+      prepare();
+#pragma unroll
+      for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
+    }
   }
+  int cur = 0, nxt = D;
+  for (int s = 0; s < nsteps; ++s) {
+    if (D >= 2 && s + 1 < nsteps) {
+      if constexpr (NLOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur, s + D < nsteps, nxt, s + D);
+    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
+  }
+  __syncthreads();
 
   // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
   constexpr int CROW = BN * (int)sizeof(T) + 16;            // padded C-tile row
@@ -248,7 +321,7 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
   __syncthreads();
   constexpr int CPR = BN / EPP;                              // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
-  for (int q = tid; q < BM * CPR; q += 256) {
+  for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
     const int p = p_base + row;
     const int k = n0 + pc * EPP;
@@ -268,34 +341,43 @@ __global__ __launch_bounds__(256) void gconv_kernel(const GDesc d, const T* __re
 }
 
 // ------------------------------------------------------------------------------------------------------
-// weight gradient:  dWp[m][t*Cg + c] (+)= sum_p rows[p][m] * gather[pix(p,t)][c]
+// weight gradient:  dWp[split][m][t*Cg + c] = sum_{p in split} rows[p][m] * gather[pix(p,t)][c]
 //   rows   : [N*Hg*Wg][Cp_r]   the tensor on the pixel grid (dy for Conv2d, x for ConvTranspose2d)
 //   gather : [N,Hin,Win,Cp_in] the tensor reached through the taps
+// Tile TM x 256 (TM = 128, or 32 for folded 2-channel layers), 64 (bf16) / 32 (f32) pixels per K step, 8 waves,
+// 3-slot LDS ring fed by buffer_load ... lds with the next-but-one tile's pieces issued between MFMA clusters.
+// The pixel reduction is split over blockIdx.z; every split writes its own slab (plain stores) and the unpack
+// kernel adds the slabs in a fixed order: no float atomics, bit-reproducible gradients.
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int TM>
-__global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
-                                                    float* __restrict__ dwp, int Cp_r, int steps_per_split, int use_atomic) {
+__global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
+                                                    float* __restrict__ dwp, int Cp_r, int steps_per_split, long slab_elems,
+                                                    unsigned rows_bytes) {
   constexpr int EPP = Elem<T>::EPP;
-  constexpr int BKP = sizeof(T) == 2 ? 64 : 32;             // pixels per K-step
-  constexpr int TN = 128;
+  constexpr int SZ = (int)sizeof(T);
+  constexpr int NT = 512;
+  constexpr int BKP = SZ == 2 ? 64 : 32;                    // pixels per K-step
+  constexpr int TN = 256;
   static_assert(TM == 128 || TM == 32, "row tile");
-  constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 4 / WAVES_M;
+  constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 8 / WAVES_M;
   constexpr int MI = TM / WAVES_M / 32, NI = TN / WAVES_N / 32;
   // gather-operand tile [BKP][TN]
-  constexpr int ROWB = TN * (int)sizeof(T);                 // 256 B (bf16) / 512 B (f32) LDS rows, unpadded
+  constexpr int ROWB = TN * SZ;                             // 512 B (bf16) / 1024 B (f32) LDS rows
   constexpr int TILE = BKP * ROWB;
-  constexpr int CPR = TN / EPP;                             // 16-byte pieces per row: 16 / 32
-  constexpr int PPT = BKP * CPR / 256;                      // pieces per thread per tile (4)
-  constexpr int RSTEP = 256 / CPR;                          // row distance between a thread's pieces
-  constexpr int RPW = 64 / CPR;                             // rows one wave instruction fills: 4 / 2
+  constexpr int CPR = TN / EPP;                             // 16-byte pieces per row: 32 / 64
+  constexpr int PPT = BKP * CPR / NT;                       // pieces per thread per tile
+  constexpr int RSTEP = NT / CPR;                           // row distance between a thread's pieces
+  static_assert(PPT == 4, "four gather pieces per thread");
   // rows-operand tile [BKP][TM]
-  constexpr int ROWA = TM * (int)sizeof(T);
+  constexpr int ROWA = TM * SZ;
   constexpr int TILEA = BKP * ROWA;
   constexpr int CPRA = TM / EPP;
-  constexpr int PPTA = BKP * CPRA / 256;                    // 4 (TM 128) or 1 (TM 32)
-  constexpr int RSTEPA = 256 / CPRA;
-  constexpr int RPWA = 64 / CPRA;
+  constexpr int PPTA = (BKP * CPRA + NT - 1) / NT;          // 2 (TM 128) or 1 on half the threads (TM 32)
+  constexpr int RSTEPA = NT / CPRA;
   constexpr int STAGE = TILE + TILEA;
+  constexpr int NSTAGE = 3;
+  constexpr int NLOADS = PPT + PPTA;
+  constexpr unsigned kOOB = 0xFFFFFFF0u;
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
@@ -313,19 +395,21 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
   const int s_begin = blockIdx.z * steps_per_split;
   int s_end = s_begin + steps_per_split;
   if (s_end > total_steps) s_end = total_steps;
-  if (s_begin >= s_end) return;
+  const int nsteps = s_end - s_begin;                       // >= 1 by construction of the grid
 
-  // Direct global -> LDS staging: one wave instruction fills RPW consecutive tile rows linearly.  bf16 tiles are
-  // read back with the transposing ds_read_b64_tr_b16, whose 32-lane half touches 4 pixel rows x 64 B: the 16-byte
-  // chunk index is XORed with (row & 3) << 2 so the four rows land in different quarters of the 256-byte bank row.
-  // As in gconv the swizzle is applied to the per-lane SOURCE column.
-  const int rb = tid / CPR;                                 // tile rows rb + RSTEP * i
-  const int slot = tid % CPR;
-  const int chunk = sizeof(T) == 2 ? (slot ^ ((rb & 3) << 2)) : slot;
-  const T* zero = reinterpret_cast<const T*>(g_zero_page);
-  const int rbA = tid / CPRA, slotA = tid % CPRA;
-  const int chunkA = (sizeof(T) == 2 && TM == 128) ? (slotA ^ ((rbA & 3) << 2)) : slotA;
-  const int mcol = m0 + chunkA * EPP;                       // rows-operand column, fixed per thread
+  // Staging: one wave instruction fills 1 KiB of consecutive tile rows.  bf16 tiles are read back with the transposing
+  // ds_read_b64_tr_b16, whose 32-lane half touches 4 pixel rows x 64 B: the 16-byte chunk index is XORed with
+  // (row & 3) << 2 so the four rows land in different quarters of the 256-byte bank row (swizzle on the SOURCE column).
+  const int rb = tid / CPR, slot = tid % CPR;               // gather tile rows rb + RSTEP * i
+  const int chunk = SZ == 2 ? (slot ^ ((rb & 3) << 2)) : slot;
+  // rows tile: when it has fewer pieces than threads (TM = 32) the upper waves re-load the lower waves' pieces, so every
+  // wave has the same number of loads in flight and one counted vmcnt serves all
+  constexpr int APIECES = BKP * CPRA;
+  const int tidA = APIECES >= NT ? tid : (tid & (APIECES - 1));
+  const int waveA = APIECES >= NT ? wave : (wave & (APIECES / 64 - 1));
+  const int rbA = tidA / CPRA, slotA = tidA % CPRA;         // rows tile rows rbA + RSTEPA * i
+  const int chunkA = (SZ == 2 && TM == 128) ? (slotA ^ ((rbA & 3) << 2)) : slotA;
+  const int mcol = m0 + chunkA * EPP;
   const bool mvalid = mcol < Cp_r;
   const int kk = j0 + chunk * EPP;                          // gather-operand (tap, channel), fixed per thread
   const int T_taps = d.nth * d.ntw;
@@ -334,9 +418,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
   const int ta = g_t / d.ntw, tb = g_t - ta * d.ntw;
   const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  typedef const __attribute__((address_space(1))) void* gbl_ptr;
+  const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gat, 0, (int)d.in_bytes, 0x00020000);
+  const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, (int)rows_bytes, 0x00020000);
+  // rows operand: byte offset of each piece, advanced by one K step per tile; pixels past the end load zeros (the
+  // buffer range check does not see scalar offsets, so the tail is tested here)
+  long pA = (long)s_begin * BKP + rbA;
+  unsigned offA = (unsigned)(((size_t)pA * Cp_r + mcol) * SZ), vA[PPTA];
+  const unsigned a_step_bytes = (unsigned)(BKP * Cp_r * SZ), a_row_bytes = (unsigned)(RSTEPA * Cp_r * SZ);
 
-  // per-piece pixel coordinates, advanced incrementally (no division in the loop)
+  // per-piece pixel coordinates of the gather operand, advanced incrementally (no division in the loop)
   int pn0, pn1, pn2, pn3, ph0, ph1, ph2, ph3, pw0, pw1, pw2, pw3;
   long pbase = (long)s_begin * BKP + rb;
   {
@@ -350,43 +440,45 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
     split(pbase + 2 * RSTEP, pn2, ph2, pw2);
     split(pbase + 3 * RSTEP, pn3, ph3, pw3);
   }
-  static_assert(PPT == 4, "four pieces per thread");
+  unsigned vG[4];
 
-#define P2PHD_WG_PIECE(I, PN, PH, PW)                                                                        \
+#define P2PHD_WG_PREP(I, PN, PH, PW)                                                                         \
   {                                                                                                          \
-    const T* s2 = zero;                                                                                      \
-    const long pp = pbase + (I) * RSTEP;                                                                     \
-    if (pp < P) {                                                                                            \
-      if (gvalid) {                                                                                          \
-        int hi = PH * sh + dh, wi = PW * sw + dw;                                                            \
-        if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }                         \
-        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) s2 = gat + ((size_t)(PN * Hin + hi) * Win + wi) * Cpi + g_c; \
-      }                                                                                                      \
+    unsigned off = kOOB;                                                                                     \
+    if (gvalid && pbase + (I) * RSTEP < P) {                                                                 \
+      int hi = PH * sh + dh, wi = PW * sw + dw;                                                              \
+      if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }                           \
+      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)                                                        \
+        off = ((unsigned)((PN * Hin + hi) * Win + wi) * (unsigned)Cpi + (unsigned)g_c) * (unsigned)SZ;       \
     }                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gbl_ptr)s2, (lds_ptr)(G + (I) * RSTEP * ROWB), 16, 0, 0);             \
+    vG[I] = off;                                                                                             \
     PW += BKP;                                                                                               \
     while (PW >= Wg) { PW -= Wg; ++PH; }                                                                     \
     while (PH >= Hg) { PH -= Hg; ++PN; }                                                                     \
   }
-
-  long pstep = (long)s_begin * BKP;
-  auto issue = [&](int stage) {
-    char* A = smem + stage * STAGE + (RPWA * wave) * ROWA;
-    char* G = smem + stage * STAGE + TILEA + (RPW * wave) * ROWB;
+  auto prepare = [&]() {
 #pragma unroll
-    for (int i = 0; i < PPTA; ++i) {
-      const long pa = pstep + rbA + RSTEPA * i;
-      const T* s1 = (mvalid && pa < P) ? rows + (size_t)pa * Cp_r + mcol : zero;
-      __builtin_amdgcn_global_load_lds((gbl_ptr)s1, (lds_ptr)(A + i * RSTEPA * ROWA), 16, 0, 0);
-    }
-    pstep += BKP;
-    P2PHD_WG_PIECE(0, pn0, ph0, pw0)
-    P2PHD_WG_PIECE(1, pn1, ph1, pw1)
-    P2PHD_WG_PIECE(2, pn2, ph2, pw2)
-    P2PHD_WG_PIECE(3, pn3, ph3, pw3)
+    for (int i = 0; i < PPTA; ++i) vA[i] = (mvalid && pA + RSTEPA * i < P) ? offA + i * a_row_bytes : kOOB;
+    pA += BKP;
+    offA += a_step_bytes;
+    P2PHD_WG_PREP(0, pn0, ph0, pw0)
+    P2PHD_WG_PREP(1, pn1, ph1, pw1)
+    P2PHD_WG_PREP(2, pn2, ph2, pw2)
+    P2PHD_WG_PREP(3, pn3, ph3, pw3)
     pbase += BKP;
   };
-#undef P2PHD_WG_PIECE
+#undef P2PHD_WG_PREP
+  // piece j of tile `tile` (index relative to s_begin): 0..3 gather rows, 4.. rows-operand rows
+  auto issue_piece = [&](int slot_, int tile, int j) {
+    char* A = smem + slot_ * STAGE;
+    if (j < 4) {
+      char* G = A + TILEA + (size_t)((64 / CPR) * wave) * ROWB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)(G + j * RSTEP * ROWB), 16, (int)vG[j], 0, 0, 0);
+    } else {
+      char* Aw = A + (size_t)((64 / CPRA) * waveA) * ROWA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(Aw + (j - 4) * RSTEPA * ROWA), 16, (int)vA[j - 4], 0, 0, 0);
+    }
+  };
 
   f32x16 acc[MI][NI];
 #pragma unroll
@@ -396,44 +488,81 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  auto compute = [&](int stage) {
-    const char* A = smem + stage * STAGE;
-    const char* G = A + TILEA;
-    if constexpr (sizeof(T) == 2) {
-      // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i.
-      // lane 4q+p of the group supplies row (8h + q), logical 8-byte column unit u = 4*(g&1) + p  (u>>1 = 16-B chunk)
-      const int g = lane >> 4, i16 = lane & 15, q = i16 >> 2, pq = i16 & 3, h = g >> 1;
-      const int u = 4 * (g & 1) + pq;
-      const int swz = q << 2;                                // (row & 3) << 2 with row = 16 sub + 8 h + q (+4)
-      const int swzA = TM == 128 ? swz : 0;
-      typedef __attribute__((address_space(3))) s16x4* trp;
+  const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i; lane 4q+p of the
+  // group supplies row (8h + q), logical 8-byte column unit u = 4*(g&1) + p  (u>>1 = 16-B chunk)
+  const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3, hh = g16 >> 1;
+  const int u8 = 4 * (g16 & 1) + pq;
+  const int swz = q4 << 2;                                  // (row & 3) << 2 with row = 16 sub + 8 h + q (+4)
+  const int swzA = TM == 128 ? swz : 0;
+  unsigned ta_off[MI], tg_off[NI];                          // byte offsets (within a stage) of the sub = 0 reads
 #pragma unroll
-      for (int sub = 0; sub < BKP / 16; ++sub) {
-        const int prow = 16 * sub + 8 * h + q;
-        bf16x8 af[MI], gf[NI];
+  for (int i = 0; i < MI; ++i) {
+    const int ca = (wm * (MI * 32) + i * 32) / 8 + (u8 >> 1);
+    ta_off[i] = (unsigned)((8 * hh + q4) * ROWA + ((ca ^ swzA) << 4) + 8 * (u8 & 1));
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int cg = (wn * (NI * 32) + j * 32) / 8 + (u8 >> 1);
+    tg_off[j] = (unsigned)(TILEA + (8 * hh + q4) * ROWB + ((cg ^ swz) << 4) + 8 * (u8 & 1));
+  }
+
+  auto compute = [&](int slot_, bool pf, int pf_slot, int pf_tile) {
+    if (pf) prepare();
+    if constexpr (SZ == 2) {
+      const unsigned so = sbase + (unsigned)(slot_ * STAGE);
+      uint2 af[2][MI][2], gf[2][NI][2];
+      auto read_frags = [&](int sub, int buf) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const int ca = (wm * (MI * 32) + i * 32) / 8 + (u >> 1);  // logical chunk
-          const char* pa = A + prow * ROWA + ((ca ^ swzA) << 4) + 8 * (u & 1);
-          s16x4* ad = reinterpret_cast<s16x4*>(&af[i]);
-          ad[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pa));
-          ad[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pa + 4 * ROWA));
+          const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * ROWA);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][0]) : "v"(ad));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * ROWA));
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          const int cg = (wn * (NI * 32) + j * 32) / 8 + (u >> 1);
-          const char* pg = G + prow * ROWB + ((cg ^ swz) << 4) + 8 * (u & 1);
-          s16x4* gd = reinterpret_cast<s16x4*>(&gf[j]);
-          gd[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pg));
-          gd[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((trp)(pg + 4 * ROWB));
+          const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * ROWB);
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][0]) : "v"(ad));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * ROWB));
         }
+      };
+      read_frags(0, 0);
+#pragma unroll
+      for (int sub = 0; sub < BKP / 16; ++sub) {
+        const int buf = sub & 1;
+        if (pf) {
+#pragma unroll
+          for (int j = sub; j < NLOADS; j += BKP / 16) issue_piece(pf_slot, pf_tile, j);
+        }
+        if (sub + 1 < BKP / 16) {
+          read_frags(sub + 1, buf ^ 1);
+          if constexpr (MI + NI == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], gf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NI; ++j) {
+            bf16x8 a8, g8;
+            uint2* ap = reinterpret_cast<uint2*>(&a8);
+            uint2* gp = reinterpret_cast<uint2*>(&g8);
+            ap[0] = af[buf][i][0]; ap[1] = af[buf][i][1];
+            gp[0] = gf[buf][j][0]; gp[1] = gf[buf][j][1];
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, g8, acc[i][j], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
+      // f32 (parity runs): plain LDS reads; hipcc drains the DMA queue in front of them, which is correct, just slower
+      if (pf) {
+#pragma unroll
+        for (int j = 0; j < NLOADS; ++j) issue_piece(pf_slot, pf_tile, j);
+      }
+      const char* A = smem + slot_ * STAGE;
+      const char* G = A + TILEA;
       const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll 4
       for (int s2 = 0; s2 < BKP / 2; ++s2) {
@@ -452,16 +581,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
     }
   };
 
-  issue(0);
-  __syncthreads();
-  int st = 0;
-  for (int s = s_begin; s < s_end; ++s) {
-    if (s + 1 < s_end) issue(st ^ 1);
-    compute(st);
-    __syncthreads();
-    st ^= 1;
+  constexpr int D = NSTAGE - 1;
+#pragma unroll
+  for (int t = 0; t < D; ++t) {
+    if (t < nsteps) {
+      prepare();
+#pragma unroll
+      for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
+    }
+  }
+  int cur = 0, nxt = D;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) {
+      if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    compute(cur, s + D < nsteps, nxt, s + D);
+    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
   }
 
+  float* slab = dwp + (size_t)blockIdx.z * slab_elems;
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -472,9 +616,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const GDesc d, const T* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float* dst = dwp + (size_t)row * KK + col;
-        if (use_atomic) atomicAdd(dst, acc[i][j][e]);
-        else *dst = acc[i][j][e];
+        slab[(size_t)row * KK + col] = acc[i][j][e];
       }
     }
 }
@@ -500,7 +642,8 @@ __global__ void pack_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w,
   }
 }
 
-__global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp, float* __restrict__ dw) {
+__global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp, float* __restrict__ dw, int splits,
+                                   long slab_elems) {
   const int T_taps = d.nth * d.ntw;
   const long total = (long)m.rows * T_taps * m.inner;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -510,8 +653,10 @@ __global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restri
     const int row = (int)(r2 / T_taps);
     const int ta = t / d.ntw, tb = t - ta * d.ntw;
     const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
-    dw[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s] =
-        dwp[(size_t)row * d.KK + t * d.Cp_in + c];
+    const float* src = dwp + (size_t)row * d.KK + t * d.Cp_in + c;
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += src[(size_t)z * slab_elems];        // fixed order: reproducible
+    dw[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s] = v;
   }
 }
 
@@ -598,20 +743,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int BN, int WGM, int WGN, int MR, int NR>
+template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
 int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
                      float* stats, hipStream_t st) {
-  constexpr int STAGE = (kBM + BN) * kRowBytes;
-  constexpr int CT = kBM * (BN * (int)sizeof(T) + 16);
-  const int tab = (d.nth * d.ntw * kBM * 4 + 15) & ~15;
-  const size_t lds = tab + (size_t)(2 * STAGE > CT ? 2 * STAGE : CT);
-  auto kern = gconv_kernel<T, BN, WGM, WGN, MR, NR>;
+  constexpr int STAGE = (BM + BN) * kRowBytes;
+  constexpr int CT = BM * (BN * (int)sizeof(T) + 16);
+  const int tab = (d.nth * d.ntw * BM * 4 + 15) & ~15;
+  const size_t lds = tab + (size_t)(NSTAGE * STAGE > CT ? NSTAGE * STAGE : CT);
+  auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int mtiles = (d.Hg * d.Wg + kBM - 1) / kBM;
+  const int mtiles = (d.Hg * d.Wg + BM - 1) / BM;
   const int ntiles = (d.Cp_out + BN - 1) / BN;
   dim3 grid((unsigned)(mtiles * d.N), (unsigned)ntiles);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
+  hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
   return p2phd::check_launch("gconv");
 }
 
@@ -622,18 +767,38 @@ int launch_gconv_t(const GDesc& d, const void* in, const void* wp, const float* 
   // narrower tiles only for layers that would leave most of it empty
   const int k = d.Cp_out;
   const int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
-  if (bn == 128) return launch_gconv_cfg<T, 128, 2, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
-  if (bn == 64) return launch_gconv_cfg<T, 64, 2, 2, 2, 1>(d, in, wp, bias, addend, out, stats, st);
-  return launch_gconv_cfg<T, 32, 4, 1, 1, 1>(d, in, wp, bias, addend, out, stats, st);
+  const int npix = d.Hg * d.Wg;
+  const int taps = d.nth * d.ntw;
+  // 256-row tiles (8 waves, 3-slot ring) halve the weight traffic per FLOP: used when a sample has enough pixels to
+  // fill them, the grid still covers the chip, and ring + gather table fit the 160 KiB of LDS
+  const long wg256 = (long)((npix + 255) / 256) * d.N * ((k + bn - 1) / bn);
+  const bool fits = bn >= 64 && 3 * (256 + bn) * kRowBytes + taps * 256 * 4 + 16 <= 160 * 1024;
+  bool big = fits && npix >= 256 && (npix % 256 == 0 || npix >= 2048) && wg256 >= 256;
+  if (p2phd::g_opt_gconv_bm == 128) big = false;
+  if (p2phd::g_opt_gconv_bm == 256) big = fits;
+  if (big && bn == 128) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
+  if (big && bn == 64) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st);
+  if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
+  if (bn == 64) return launch_gconv_cfg<T, 128, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st);
+  return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st);
 }
 
 }  // namespace
 
 namespace p2phd {
 
-int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
+int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
                  void* out, float* stats, hipStream_t st) {
-  if (d.N == 0 || d.Hg * d.Wg == 0) return P2PHD_OK;
+  if (d_in.N == 0 || d_in.Hg * d_in.Wg == 0) return P2PHD_OK;
+  GDesc d = d_in;
+  {
+    const size_t esz = dtype == P2PHD_BF16 ? 2 : 4;
+    const size_t ib = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz;
+    const size_t wb = (size_t)round_up(d.Cp_out, 128) * d.KK * esz;   // packed rows are padded to 128
+    P2PHD_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "gconv: tensor larger than 4 GiB");
+    d.in_bytes = (unsigned)ib;
+    d.w_bytes = (unsigned)wb;
+  }
   P2PHD_REQUIRE(d.Cp_in % 8 == 0 && d.Cp_out % 8 == 0, "gconv: channel pitch must be a multiple of 8");
   P2PHD_REQUIRE((long)d.N * d.Hin * d.Win < (1l << 31) && (long)d.N * d.Hout * d.Wout < (1l << 31), "gconv: too many pixels");
   if (dtype == P2PHD_BF16) return launch_gconv_t<bf16_t>(d, in, wp, bias, addend, out, stats, st);
@@ -643,47 +808,69 @@ int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, cons
 }
 
 template <typename T, int TM>
-void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* dwp, int Cp_r, int M_rows_pad, int sps,
-                      int splits, int use_atomic, hipStream_t st) {
+void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* dwp, int Cp_r, int mrows, int sps, int splits,
+                      long slab_elems, unsigned rows_bytes, hipStream_t st) {
   constexpr int bkp = sizeof(T) == 2 ? 64 : 32;
-  constexpr int lds = 2 * bkp * (128 + TM) * (int)sizeof(T);
+  constexpr int lds = 3 * bkp * (256 + TM) * (int)sizeof(T);
   auto kern = wgrad_kernel<T, TM>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  dim3 grid((unsigned)((d.KK + 127) / 128), (unsigned)(M_rows_pad / TM), (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, use_atomic);
+  dim3 grid((unsigned)((d.KK + 255) / 256), (unsigned)(mrows / TM), (unsigned)splits);
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, slab_elems, rows_bytes);
 }
 
-int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad, const void* gat,
-                 float* dwp, hipStream_t st) {
-  // dwp: [M_rows_pad][KK] f32, M_rows_pad a multiple of 128; M_rows = rows that carry data
+// Split plan of the pixel reduction: shared by the workspace query and the launch.
+void wgrad_split_plan(const GDesc& d, int dtype, int M_rows, int M_rows_pad, int* tm, int* mrows, int* splits, int* sps) {
   const long P = (long)d.N * d.Hg * d.Wg;
   const int bkp = dtype == P2PHD_BF16 ? 64 : 32;
-  const int total_steps = (int)((P + bkp - 1) / bkp);
-  const int tm = M_rows <= 32 ? 32 : 128;                       // narrow row tile for folded 2-channel layers
-  const int mrows = tm == 32 ? 32 : M_rows_pad;
-  const int tiles = (mrows / tm) * ((d.KK + 127) / 128);
-  if (total_steps == 0) {
-    (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)M_rows_pad * d.KK, st);
-    return P2PHD_OK;
-  }
-  // split the pixel reduction until the grid covers the chip ~3x, keeping >= 8 steps per split
-  int splits = 1;
-  while (tiles * splits < 768 && total_steps / (splits * 2) >= 8) splits *= 2;
-  const int sps = (total_steps + splits - 1) / splits;
-  splits = (total_steps + sps - 1) / sps;
-  const int use_atomic = splits > 1;
-  if (use_atomic) (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)mrows * d.KK, st);
-  if (dtype == P2PHD_BF16) {
-    if (tm == 32) launch_wgrad_cfg<bf16_t, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
-    else launch_wgrad_cfg<bf16_t, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
+  const int total_steps = (int)std::max<long>(1, (P + bkp - 1) / bkp);
+  *tm = M_rows <= 32 ? 32 : 128;                              // narrow row tile for folded 2-channel layers
+  *mrows = *tm == 32 ? 32 : M_rows_pad;
+  const int tiles = (*mrows / *tm) * ((d.KK + 255) / 256);
+  // split until the grid covers the chip ~2x (8-wave workgroups, one per CU), keeping >= 8 steps per split and the
+  // slab workspace under 256 MiB
+  int sp = 1;
+  const size_t slab_bytes = (size_t)*mrows * d.KK * sizeof(float);
+  while (tiles * sp < 512 && total_steps / (sp * 2) >= 8 && slab_bytes * (sp * 2) <= (256u << 20)) sp *= 2;
+  *sps = (total_steps + sp - 1) / sp;
+  *splits = (total_steps + *sps - 1) / *sps;
+}
+
+size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad) {
+  int tm, mrows, splits, sps;
+  wgrad_split_plan(d, dtype, M_rows, M_rows_pad, &tm, &mrows, &splits, &sps);
+  return (size_t)splits * mrows * d.KK;
+}
+
+int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
+                 const void* gat, float* dwp, float* dw, hipStream_t st) {
+  // dwp: wgrad_workspace_floats() floats; dw: master-layout gradient (overwritten)
+  GDesc d = d_in;
+  const long P = (long)d.N * d.Hg * d.Wg;
+  const size_t esz = dtype == P2PHD_BF16 ? 2 : 4;
+  const size_t gb = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz, rbytes = (size_t)P * Cp_r * esz;
+  P2PHD_REQUIRE(gb < 0xFFFFFFF0ull && rbytes < 0xFFFFFFF0ull, "wgrad: tensor larger than 4 GiB");
+  d.in_bytes = (unsigned)gb;
+  int tm, mrows, splits, sps;
+  wgrad_split_plan(d, dtype, M_rows, M_rows_pad, &tm, &mrows, &splits, &sps);
+  const long slab = (long)mrows * d.KK;
+  if (P == 0) {
+    (void)hipMemsetAsync(dwp, 0, sizeof(float) * (size_t)slab, st);
+    splits = 1;
+  } else if (dtype == P2PHD_BF16) {
+    if (tm == 32) launch_wgrad_cfg<bf16_t, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
+    else launch_wgrad_cfg<bf16_t, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
   } else if (dtype == P2PHD_F32) {
-    if (tm == 32) launch_wgrad_cfg<float, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
-    else launch_wgrad_cfg<float, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, use_atomic, st);
+    if (tm == 32) launch_wgrad_cfg<float, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
+    else launch_wgrad_cfg<float, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
   } else {
     set_error("wgrad: unsupported dtype %d", dtype);
     return P2PHD_EUNSUPPORTED;
   }
-  return check_launch("wgrad");
+  if (int rc = check_launch("wgrad")) return rc;
+  const long total = (long)m.rows * d.nth * d.ntw * m.inner;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, m, dwp, dw, splits, slab);
+  return check_launch("unpack_grad");
 }
 
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
@@ -694,13 +881,6 @@ int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* 
   else
     hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, d, m, w, (float*)wp, rows_pad);
   return check_launch("pack_weights");
-}
-
-int launch_unpack_grad(const GDesc& d, const WMap& m, const float* dwp, float* dw, hipStream_t st) {
-  const long total = (long)m.rows * d.nth * d.ntw * m.inner;
-  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, m, dwp, dw);
-  return check_launch("unpack_grad");
 }
 
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,

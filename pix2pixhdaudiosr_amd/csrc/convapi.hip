@@ -300,20 +300,39 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
   return P2PHD_OK;
 }
 
+namespace {
+// everything p2phd_conv_wgrad needs, derived once for both the workspace query and the call
+struct WgradSetup { Plan p; WMap m; int M; int Cp_r; int fold; size_t dwp_bytes; };
+void wgrad_setup(const p2phd_conv_desc* c, WgradSetup* w) {
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const long RS = (long)c->R * c->S;
+  w->fold = fold_mode(c);
+  if (w->fold == FOLD_OUT) {       // dWp[(tw,k)][th][c] = sum dyE[n,ho,w',(tw,k)] * x[n, ho+th-pad, w'-pad, c]
+    w->p = kfold_fwd_plan(c, Ho, Wo); w->m = kfold_rows_map(c); w->M = c->S * c->K; w->Cp_r = cpitch(w->M);
+  } else if (w->fold == FOLD_IN) { // dWp[k][th][(tw,c)] = sum dy[n,ho,wo,k] * Xe[n, ho+th-pad, wo, (tw,c)]
+    w->p = cfold_fwd_plan(c, Ho, Wo); w->m = cfold_map(c); w->M = c->K; w->Cp_r = cpitch(c->K);
+  } else if (!c->transposed) {     // dW[k][c][r][s] = sum dy[n,ho,wo,k] * x[n, ho*s-pad+r, wo*s-pad+s', c]
+    w->p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
+    w->m = plain_map(c->K, c->C, c->C * RS, RS, c->S); w->M = c->K; w->Cp_r = cpitch(c->K);
+  } else {                         // dW[ci][co][r][s] = sum x[n,i,j,ci] * dy[n, i*s-pad+r, j*s-pad+s', co]
+    w->p = direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0);
+    w->m = plain_map(c->C, c->K, c->K * RS, RS, c->S); w->M = c->C; w->Cp_r = cpitch(c->C);
+  }
+  w->dwp_bytes = align256(wgrad_workspace_floats(w->p.d, c->dtype, w->M, round_up(w->M, 128)) * sizeof(float));
+}
+}  // namespace
+
 extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
-  const int fold = fold_mode(c);
-  int M, KK;
+  WgradSetup w;
+  wgrad_setup(c, &w);
   size_t extra = 0;
-  if (fold == FOLD_OUT) { M = c->S * c->K; KK = std::max(64, round_up(c->R * cpitch(c->C), 64)); extra = folded_dy_bytes(c, Ho, Wo); }
-  else if (fold == FOLD_IN) { M = c->K; KK = std::max(64, round_up(c->R * cpitch(c->S * c->C), 64)); extra = folded_x_bytes(c, Wo); }
-  else {
-    M = c->transposed ? c->C : c->K;
-    KK = std::max(64, round_up(c->R * c->S * cpitch(c->transposed ? c->K : c->C), 64));
-  }
-  return align256((size_t)round_up(M, 128) * KK * sizeof(float)) + extra;
+  if (w.fold == FOLD_OUT) extra = folded_dy_bytes(c, Ho, Wo);
+  else if (w.fold == FOLD_IN) extra = folded_x_bytes(c, Wo);
+  return w.dwp_bytes + extra;
 }
 
 extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
@@ -322,41 +341,24 @@ extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const v
   P2PHD_REQUIRE(x && dy && dw && workspace, "conv_wgrad: null pointer");
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
-  const long RS = (long)c->R * c->S;
   hipStream_t st = (hipStream_t)stream;
-  const int fold = fold_mode(c);
-  Plan p;
-  WMap m;
-  const void *rows_t, *gat_t;
-  int Cp_r, M;
+  WgradSetup w;
+  wgrad_setup(c, &w);
   float* dwp = static_cast<float*>(workspace);
-  if (fold == FOLD_OUT) {       // dWp[(tw,k)][th][c] = sum dyE[n,ho,w',(tw,k)] * x[n, ho+th-pad, w'-pad, c]
-    p = kfold_fwd_plan(c, Ho, Wo);
-    m = kfold_rows_map(c);
-    M = c->S * c->K;
-    char* dye = static_cast<char*>(workspace) + align256((size_t)round_up(M, 128) * p.d.KK * sizeof(float));
-    if (int rc = launch_expand_dy(c->dtype, dy, dye, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
-    rows_t = dye; gat_t = x; Cp_r = cpitch(M);
-  } else if (fold == FOLD_IN) { // dWp[k][th][(tw,c)] = sum dy[n,ho,wo,k] * Xe[n, ho+th-pad, wo, (tw,c)]
-    p = cfold_fwd_plan(c, Ho, Wo);
-    m = cfold_map(c);
-    M = c->K;
-    char* xe = static_cast<char*>(workspace) + align256((size_t)round_up(M, 128) * p.d.KK * sizeof(float));
-    if (int rc = launch_expand_in(c->dtype, x, xe, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
-    rows_t = dy; gat_t = xe; Cp_r = cpitch(c->K);
-  } else if (!c->transposed) {  // dW[k][c][r][s] = sum dy[n,ho,wo,k] * x[n, ho*s-pad+r, wo*s-pad+s', c]
-    p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
-    m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
-    M = c->K;
-    rows_t = dy; gat_t = x; Cp_r = cpitch(c->K);
-  } else {                      // dW[ci][co][r][s] = sum x[n,i,j,ci] * dy[n, i*s-pad+r, j*s-pad+s', co]
-    p = direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0);
-    m = plain_map(c->C, c->K, c->K * RS, RS, c->S);
-    M = c->C;
-    rows_t = x; gat_t = dy; Cp_r = cpitch(c->C);
+  char* extra = static_cast<char*>(workspace) + w.dwp_bytes;
+  const void *rows_t, *gat_t;
+  if (w.fold == FOLD_OUT) {
+    if (int rc = launch_expand_dy(c->dtype, dy, extra, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
+    rows_t = extra; gat_t = x;
+  } else if (w.fold == FOLD_IN) {
+    if (int rc = launch_expand_in(c->dtype, x, extra, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
+    rows_t = dy; gat_t = extra;
+  } else if (!c->transposed) {
+    rows_t = dy; gat_t = x;
+  } else {
+    rows_t = x; gat_t = dy;
   }
-  if (int rc = launch_wgrad(p.d, c->dtype, rows_t, Cp_r, M, round_up(M, 128), gat_t, dwp, st)) return rc;
-  if (int rc = launch_unpack_grad(p.d, m, dwp, dw, st)) return rc;
+  if (int rc = launch_wgrad(w.p.d, w.m, c->dtype, rows_t, w.Cp_r, w.M, round_up(w.M, 128), gat_t, dwp, dw, st)) return rc;
   if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, st);
   return P2PHD_OK;
 }

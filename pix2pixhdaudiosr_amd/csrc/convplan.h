@@ -14,6 +14,7 @@ struct GDesc {
   int Kout, KK, act;               // valid output channels, padded GEMM-K (row length of packed weights)
   int nth, ntw, dh0, dh_step, dw0, dw_step;   // tap (a,b): offset (dh0+a*dh_step, dw0+b*dw_step)
   int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
+  unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -31,15 +32,18 @@ inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
   return WMap{rows, inner, s_row, s_inner, rows > 0 ? rows : 1, 0, inner > 0 ? inner : 1, 0, S};
 }
 
+// tuning overrides (p2phd_set_option): 0 = heuristic
+extern int g_opt_gconv_bm;
+
 inline int cpitch(int c) { return (c + 7) & ~7; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
                  void* out, float* stats, hipStream_t st);
-int launch_wgrad(const GDesc& d, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad, const void* gat,
-                 float* dwp, hipStream_t st);
+size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad);
+int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
+                 const void* gat, float* dwp, float* dw, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
-int launch_unpack_grad(const GDesc& d, const WMap& m, const float* dwp, float* dw, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st);

@@ -1,5 +1,6 @@
 // Error channel, ABI version and device query of libp2phd_hip.so.
 #include "common.h"
+#include "convplan.h"
 #include <cstring>
 
 namespace p2phd {
@@ -11,6 +12,14 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 }  // namespace p2phd
+
+namespace p2phd { int g_opt_gconv_bm = 0; }
+
+extern "C" int p2phd_set_option(const char* name, int value) {
+  if (name && !strcmp(name, "gconv_bm") && (value == 0 || value == 128 || value == 256)) { p2phd::g_opt_gconv_bm = value; return P2PHD_OK; }
+  p2phd::set_error("set_option: unknown option or value (%s = %d)", name ? name : "(null)", value);
+  return P2PHD_EINVAL;
+}
 
 extern "C" const char* p2phd_last_error(void) { return p2phd::g_err; }
 extern "C" int p2phd_abi_version(void) { return 1; }
