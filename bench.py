@@ -79,7 +79,7 @@ def host_cores():
     return max(1, min(n, 16))          # a 1-GPU box's CPU share is 16 cores
 
 
-def cpu_baseline(sample_batch=1, steps=1):
+def cpu_baseline(sample_batch=2, steps=4):
     """The CPU oracle (oracle/model.py full_step: a port of the reference step, validated against the reference in
     tests/) on the host cores, same workload at a bounded batch."""
     from oracle import model as OM
@@ -179,7 +179,7 @@ def main():
                            "kernel": "gconv_kernel<bf16,BN=128> Conv3x3 768->768 @32x16 (residual trunk)",
                            "launch_us": sec * 1e6, "flops_per_launch": flops}
         if world == 1 and not a.no_cpu_baseline:
-            log("cpu baseline (oracle, batch 1) ...")
+            log("cpu baseline (oracle, batch 2, 4 steps) ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

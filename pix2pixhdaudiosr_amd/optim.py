@@ -66,9 +66,9 @@ class FlatAdam(torch.optim.Optimizer):
     def reduce_gradients_async(self):
         """Start the gradient all-reduce (call right after backward); step() waits for it."""
         if self.world_size > 1 and self._pending is None:
-            import torch.distributed as dist
+            from .parallel_state import all_reduce_flat_async
             self._install_grad_views()
-            self._pending = dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.process_group, async_op=True)
+            self._pending = all_reduce_flat_async(self.flat_g, self.process_group)
 
     @torch.no_grad()
     def step(self, closure=None):

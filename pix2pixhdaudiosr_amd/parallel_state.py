@@ -10,6 +10,21 @@ The G-gradient all-reduce is launched right after the G backward and runs beside
 import torch
 
 
+def all_reduce_flat_async(flat_grad, process_group=None):
+    """Start the summing all-reduce of one flat gradient buffer; returns the work handle.  The buffer is reduced in
+    place; the 1/world_size scaling is folded into the Adam kernel (grad_scale).  Backend-agnostic: RCCL ('nccl') on
+    the GPUs, 'gloo' in the CPU tests."""
+    import torch.distributed as dist
+    return dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=process_group, async_op=True)
+
+
+def shard_batch(global_batch, rank, world_size):
+    """[start, stop) of this rank's slice of the minibatch (independent samples, no data-path collective)."""
+    per = global_batch // world_size
+    assert per * world_size == global_batch, "global batch must divide evenly over the ranks"
+    return rank * per, (rank + 1) * per
+
+
 def enable_data_parallel(model, world_size, process_group=None, broadcast=True):
     import torch.distributed as dist
     if broadcast:
