@@ -133,9 +133,10 @@ int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, fl
  * residual != NULL.  stats = the float [N][Cp][2] (sum, sum of squares) p2phd_conv_fwd accumulated. */
 int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
                            int N, int64_t HW, int C, float eps, int act, void* stream);
-/* dy from g = dL/d(out) through act and InstanceNorm; bstats: float [N][Cp][2] scratch (zeroed inside). */
+/* dy from g = dL/d(out) through act and InstanceNorm; bstats: float [N][Cp][2] scratch (zeroed inside).
+ * db (float [C], may be NULL): the conv bias gradient = column sums of dy, accumulated in the same pass. */
 int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
-                           int N, int64_t HW, int C, float eps, int act, void* stream);
+                           float* db, int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */
 int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream);
 

@@ -220,23 +220,27 @@ class ConvBlockFn(torch.autograd.Function):
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
         N, Ho, Wo, Cp_out = y.shape
+        need_w = (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
+        gb = torch.empty((spec.cout,), dtype=torch.float32, device=y.device) if (need_w and ctx.has_bias) else None
+        gb_done = False
         if spec.norm:
             dy = torch.empty_like(y)
             bstats = torch.empty((N, Cp_out, 2), dtype=torch.float32, device=y.device)
-            check(L.p2phd_instnorm_act_bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), N, Ho * Wo, spec.cout,
-                                           IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd")
+            # the bias gradient (column sums of dy) rides on the apply pass
+            check(L.p2phd_instnorm_act_bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo,
+                                           spec.cout, IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd")
+            gb_done = gb is not None
         elif spec.act != ACT_NONE:
             dy = torch.empty_like(y)
             check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
         else:
             dy = g
-        gx = gw = gb = None
-        need_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
-        if need_w and not ctx.skip_wgrad:
+        gx = gw = None
+        if need_w:
             gw = torch.empty(weight.shape, dtype=torch.float32, device=y.device)
-            gb = torch.empty((spec.cout,), dtype=torch.float32, device=y.device) if ctx.has_bias else None
             ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device)
-            check(L.p2phd_conv_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+            check(L.p2phd_conv_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()),
+                  "conv_wgrad")
         if ctx.needs_input_grad[0]:
             wp = spec.packed(weight, 1, d)
             gx = torch.empty_like(x)

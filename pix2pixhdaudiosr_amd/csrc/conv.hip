@@ -98,9 +98,13 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
+  // M tiling: per sample (tiles never straddle samples; needed for the InstanceNorm sums) or, when no statistics
+  // are wanted and the per-sample pixel count does not fill whole tiles, flat over all N * npix pixels
+  const bool flat = d.flat_m != 0;
   const int mtiles = (npix + BM - 1) / BM;
-  const int n = blockIdx.x / mtiles;
-  const int p_base = (blockIdx.x - n * mtiles) * BM;
+  const int n = flat ? 0 : blockIdx.x / mtiles;
+  const int p_base = flat ? blockIdx.x * BM : (blockIdx.x - n * mtiles) * BM;
+  const int p_end = flat ? d.N * npix : npix;                 // rows >= p_end are padding
   const int n0 = blockIdx.y * BN;
 
   {  // gather table: input pixel index (or -1) per (tap, tile row)
@@ -108,15 +112,17 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     const int dh0 = d.dh0, dhs = d.dh_step, dw0 = d.dw0, dws = d.dw_step;
     for (int e = tid; e < T_taps * BM; e += NT) {
       const int t = e / BM, r = e - t * BM;
-      const int p = p_base + r;
+      int p = p_base + r;
       int off = -1;
-      if (p < npix) {
+      if (p < p_end) {
+        int nn = n;
+        if (flat) { nn = p / npix; p -= nn * npix; }
         const int ho = p / Wg, wo = p - ho * Wg;
         const int ta = t / ntw, tb = t - ta * ntw;
         int hi = ho * sh + dh0 + ta * dhs;
         int wi = wo * sw + dw0 + tb * dws;
         if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
-        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (n * Hin + hi) * Win + wi;
+        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (nn * Hin + hi) * Win + wi;
       }
       tab[e] = off;
     }
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
       for (int e = 0; e < 16; ++e) {
         const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
         float v = acc[i][j][e] + bv;
-        if (p_base + row < npix) { s1 += v; s2 += v * v; }
+        if (p_base + row < p_end) { s1 += v; s2 += v * v; }
         v = apply_act(v, act);
         *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
       }
@@ -323,11 +329,13 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
-    const int p = p_base + row;
+    int p = p_base + row;
     const int k = n0 + pc * EPP;
-    if (p >= npix || k >= Cp_out) continue;
+    if (p >= p_end || k >= Cp_out) continue;
+    int nn = n;
+    if (flat) { nn = p / npix; p -= nn * npix; }
     const int ho = p / Wg, wo = p - ho * Wg;
-    const size_t opix = ((size_t)n * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo);
+    const size_t opix = ((size_t)nn * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo);
     uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
     if (addend != nullptr) {
       const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * Cp_out + k);
@@ -753,15 +761,16 @@ int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float
   auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int mtiles = (d.Hg * d.Wg + BM - 1) / BM;
+  const int npix = d.Hg * d.Wg;
+  const int mtiles = d.flat_m ? (int)(((long)d.N * npix + BM - 1) / BM) : ((npix + BM - 1) / BM) * d.N;
   const int ntiles = (d.Cp_out + BN - 1) / BN;
-  dim3 grid((unsigned)(mtiles * d.N), (unsigned)ntiles);
+  dim3 grid((unsigned)mtiles, (unsigned)ntiles);
   hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
   return p2phd::check_launch("gconv");
 }
 
 template <typename T>
-int launch_gconv_t(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
+int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
                    float* stats, hipStream_t st) {
   // N tile: the 128-wide tile has the best MFMA density (64x64 per wave) and reads the gathered A operand once;
   // narrower tiles only for layers that would leave most of it empty
@@ -771,9 +780,10 @@ int launch_gconv_t(const GDesc& d, const void* in, const void* wp, const float* 
   const int taps = d.nth * d.ntw;
   // 256-row tiles (8 waves, 3-slot ring) halve the weight traffic per FLOP: used when a sample has enough pixels to
   // fill them, the grid still covers the chip, and ring + gather table fit the 160 KiB of LDS
-  const long wg256 = (long)((npix + 255) / 256) * d.N * ((k + bn - 1) / bn);
+  d.flat_m = stats == nullptr && (npix % 256 != 0);          // no InstanceNorm sums wanted: tiles may straddle samples
+  const long wg256 = (d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N) * ((k + bn - 1) / bn);
   const bool fits = bn >= 64 && 3 * (256 + bn) * kRowBytes + taps * 256 * 4 + 16 <= 160 * 1024;
-  bool big = fits && npix >= 256 && (npix % 256 == 0 || npix >= 2048) && wg256 >= 256;
+  bool big = fits && (d.flat_m ? (long)d.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048))) && wg256 >= 192;
   if (p2phd::g_opt_gconv_bm == 128) big = false;
   if (p2phd::g_opt_gconv_bm == 256) big = fits;
   if (big && bn == 128) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);

@@ -14,6 +14,7 @@ struct GDesc {
   int Kout, KK, act;               // valid output channels, padded GEMM-K (row length of packed weights)
   int nth, ntw, dh0, dh_step, dw0, dw_step;   // tap (a,b): offset (dh0+a*dh_step, dw0+b*dw_step)
   int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
+  int flat_m;                                 // M tiles run over all N*Hg*Wg pixels (set by the launcher)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
 };
 

@@ -142,9 +142,10 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                const float* __restrict__ stats, const float* __restrict__ bstats,
-                                                               T* __restrict__ dy, long HW, int C, int Cp, float eps, int act) {
+                                                               T* __restrict__ dy, long HW, int C, int Cp, float eps, int act,
+                                                               float* __restrict__ db) {
   constexpr int EPP = Elem<T>::EPP;
-  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp], s_m1[kMaxCp], s_m2[kMaxCp];
+  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp], s_m1[kMaxCp], s_m2[kMaxCp], s_db[kMaxCp];
   const int n = blockIdx.y;
   const float inv = 1.f / (float)HW;
   for (int c = threadIdx.x; c < Cp; c += 256) {
@@ -155,14 +156,19 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
       r = rsqrtf(fmaxf(stats[i + 1] * inv - m * m, 0.f) + eps);
       m1 = bstats[i] * inv; m2 = bstats[i + 1] * inv;
     }
-    s_mean[c] = m; s_rstd[c] = r; s_m1[c] = m1; s_m2[c] = m2;
+    s_mean[c] = m; s_rstd[c] = r; s_m1[c] = m1; s_m2[c] = m2; s_db[c] = 0.f;
   }
   __syncthreads();
   const int cpr = Cp / EPP;
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
+  // The host picks gridDim.x so that the stride (gridDim.x * 256) is a multiple of cpr: every thread then stays on
+  // one group of EPP channels and can keep the bias-gradient partial sums (column sums of dy) in registers.
+  float bsum[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) bsum[k] = 0.f;
+  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int pc = (int)(e % cpr);
     const size_t o = base + (size_t)e * EPP;
     const uint4 gv = *reinterpret_cast<const uint4*>(g + o);
     const uint4 yv = *reinterpret_cast<const uint4*>(y + o);
@@ -176,8 +182,15 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
       const float yh = (to_f(yy[k]) - s_mean[c]) * s_rstd[c];
       const float gp = to_f(gg[k]) * act_slope(yh, act);
       oo[k] = from_f<T>(c < C ? s_rstd[c] * (gp - s_m1[c] - yh * s_m2[c]) : 0.f);
+      bsum[k] += to_f(oo[k]);                                   // what the next kernels read, i.e. the rounded dy
     }
     *reinterpret_cast<uint4*>(dy + o) = ov;
+  }
+  if (db != nullptr) {
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) atomicAdd(&s_db[pc * EPP + k], bsum[k]);     // LDS atomics
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&db[c], s_db[c]);
   }
 }
 
@@ -336,7 +349,7 @@ extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* sta
 }
 
 extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
-                                      int N, int64_t HW, int C, float eps, int act, void* stream) {
+                                      float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
   const int Cp = (C + 7) & ~7;
   P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
   if (N == 0 || HW == 0) return P2PHD_OK;
@@ -356,10 +369,18 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
              hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act, cpg),
              "instnorm_act_bwd");
   if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
-  dim3 grid(grid_for(HW * cpr, 2048), N);
+  // stride (gx * 256) must be a multiple of cpr so a thread keeps its channel group: gx = multiple of cpr / gcd(cpr, 256)
+  int gcd = cpr, b256 = 256;
+  while (b256) { const int t = gcd % b256; gcd = b256; b256 = t; }
+  const int unit = cpr / gcd;
+  // few fat blocks (<= ~2048 over all samples): each ends with one global atomic per channel for the bias gradient
+  int gx = std::min(grid_for(HW * cpr, 2048), std::max(1, 2048 / std::max(N, 1)));
+  gx = std::max(unit, gx / unit * unit);
+  dim3 grid(gx, N);
+  if (db != nullptr) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act),
-             hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act),
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act, db),
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act, db),
              "instnorm_act_bwd");
   return p2phd::check_launch("instnorm_act_bwd(apply)");
 }
