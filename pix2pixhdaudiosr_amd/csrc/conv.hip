@@ -238,7 +238,8 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
       }
       if (ks < 3) {
         read_frags(ks + 1, buf ^ 1);
-        if constexpr (MR + NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        if constexpr (MR + NR == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if constexpr (MR + NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         else if constexpr (MR + NR == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
       } else {
@@ -786,6 +787,14 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   bool big = fits && (d.flat_m ? (long)d.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048))) && wg256 >= 192;
   if (p2phd::g_opt_gconv_bm == 128) big = false;
   if (p2phd::g_opt_gconv_bm == 256) big = fits;
+  // 256 x 256 tiles (8 waves of 128 x 64, 2-slot ring): twice the MFMA work per LDS-DMA piece; for wide layers whose
+  // grid still fills most of the chip
+  const long wg256x256 = (d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N) * ((k + 255) / 256);
+  bool huge = big && k >= 256 && (k % 256 == 0 || k >= 1024) && wg256x256 >= 160 &&
+              2 * 512 * kRowBytes + taps * 256 * 4 + 16 <= 160 * 1024 && 256 * (256 * (int)sizeof(T) + 16) + taps * 256 * 4 + 16 <= 160 * 1024;
+  if (p2phd::g_opt_gconv_bm == 512) huge = fits && k > 128 && sizeof(T) == 2;
+  if (p2phd::g_opt_gconv_bm != 0 && p2phd::g_opt_gconv_bm != 512) huge = false;
+  if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st);
   if (big && bn == 128) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
   if (big && bn == 64) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st);
   if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);

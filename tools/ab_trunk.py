@@ -18,9 +18,9 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
     L = _ops.lib()
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), None, _ops.stream_ptr()))
     flops = 2.0 * batch * Ho * Wo * cin * cout * k * k
-    res = {128: [], 256: []}
+    res = {128: [], 256: [], 512: []}
     for r in range(rounds):
-        for bm in (128, 256):
+        for bm in (128, 256, 512):
             _lib.check(L.p2phd_set_option(b"gconv_bm", bm))
             call(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
