@@ -367,24 +367,26 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
   constexpr int NT = 512;
   constexpr int BKP = SZ == 2 ? 64 : 32;                    // pixels per K-step
   constexpr int TN = 256;
-  static_assert(TM == 128 || TM == 32, "row tile");
-  constexpr int WAVES_M = TM == 128 ? 2 : 1, WAVES_N = 8 / WAVES_M;
+  static_assert(TM == 256 || TM == 128 || TM == 32, "row tile");
+  constexpr int WAVES_M = TM == 32 ? 1 : 2, WAVES_N = 8 / WAVES_M;
   constexpr int MI = TM / WAVES_M / 32, NI = TN / WAVES_N / 32;
-  // gather-operand tile [BKP][TN]
-  constexpr int ROWB = TN * SZ;                             // 512 B (bf16) / 1024 B (f32) LDS rows
-  constexpr int TILE = BKP * ROWB;
-  constexpr int CPR = TN / EPP;                             // 16-byte pieces per row: 32 / 64
-  constexpr int PPT = BKP * CPR / NT;                       // pieces per thread per tile
-  constexpr int RSTEP = NT / CPR;                           // row distance between a thread's pieces
+  // LDS image: both operands are stored as PANELS of [BKP pixel rows][128 bytes] (64 bf16 / 32 f32 columns), the same
+  // shape as the gconv tiles: a wave instruction of the direct-to-LDS load fills 8 rows of one panel linearly and
+  // every thread owns ONE pixel row (all its pieces are that pixel at different column panels), so the gather
+  // coordinates are advanced once per thread and K step.
+  constexpr int PANEL = BKP * 128;
+  constexpr int CPP = 128 / SZ;                             // columns per panel
+  constexpr int GROUPS = NT / (8 * BKP);                    // 1 (bf16) / 2 (f32) thread groups per row set
+  constexpr int NPG = TN / CPP;                             // gather panels: 4 / 8
+  constexpr int PPT = NPG / GROUPS;                         // gather pieces per thread
   static_assert(PPT == 4, "four gather pieces per thread");
-  // rows-operand tile [BKP][TM]
-  constexpr int ROWA = TM * SZ;
-  constexpr int TILEA = BKP * ROWA;
-  constexpr int CPRA = TM / EPP;
-  constexpr int PPTA = (BKP * CPRA + NT - 1) / NT;          // 2 (TM 128) or 1 on half the threads (TM 32)
-  constexpr int RSTEPA = NT / CPRA;
+  constexpr bool kNarrowA = TM == 32 && SZ == 2;            // rows tile [64][64 B]: half-panel rows, own mapping
+  constexpr int NPA = kNarrowA ? 1 : (TM / CPP);            // rows-operand panels
+  constexpr int PPTA = kNarrowA ? 1 : (NPA >= GROUPS ? NPA / GROUPS : 1);
+  constexpr int TILEA = kNarrowA ? BKP * 64 : NPA * PANEL;
+  constexpr int TILE = NPG * PANEL;
   constexpr int STAGE = TILE + TILEA;
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = TM == 256 ? 2 : 3;
   constexpr int NLOADS = PPT + PPTA;
   constexpr unsigned kOOB = 0xFFFFFFF0u;
 
@@ -406,86 +408,104 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
   if (s_end > total_steps) s_end = total_steps;
   const int nsteps = s_end - s_begin;                       // >= 1 by construction of the grid
 
-  // Staging: one wave instruction fills 1 KiB of consecutive tile rows.  bf16 tiles are read back with the transposing
-  // ds_read_b64_tr_b16, whose 32-lane half touches 4 pixel rows x 64 B: the 16-byte chunk index is XORed with
-  // (row & 3) << 2 so the four rows land in different quarters of the 256-byte bank row (swizzle on the SOURCE column).
-  const int rb = tid / CPR, slot = tid % CPR;               // gather tile rows rb + RSTEP * i
-  const int chunk = SZ == 2 ? (slot ^ ((rb & 3) << 2)) : slot;
-  // rows tile: when it has fewer pieces than threads (TM = 32) the upper waves re-load the lower waves' pieces, so every
-  // wave has the same number of loads in flight and one counted vmcnt serves all
-  constexpr int APIECES = BKP * CPRA;
-  const int tidA = APIECES >= NT ? tid : (tid & (APIECES - 1));
-  const int waveA = APIECES >= NT ? wave : (wave & (APIECES / 64 - 1));
-  const int rbA = tidA / CPRA, slotA = tidA % CPRA;         // rows tile rows rbA + RSTEPA * i
-  const int chunkA = (SZ == 2 && TM == 128) ? (slotA ^ ((rbA & 3) << 2)) : slotA;
-  const int mcol = m0 + chunkA * EPP;
-  const bool mvalid = mcol < Cp_r;
-  const int kk = j0 + chunk * EPP;                          // gather-operand (tap, channel), fixed per thread
-  const int T_taps = d.nth * d.ntw;
-  const int g_t = kk / Cpi, g_c = kk - g_t * Cpi;
-  const bool gvalid = g_t < T_taps;
-  const int ta = g_t / d.ntw, tb = g_t - ta * d.ntw;
-  const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
+  // this thread's pixel row, slot and panel group; bf16 tiles are read back with the transposing ds_read_b64_tr_b16,
+  // whose 32-lane half touches 4 pixel rows x 64 B at a 128-byte row pitch: rows 2,3 (mod 4) are moved to the other
+  // half of the row by XORing the 16-byte chunk index with 4 (applied to the SOURCE column, the LDS side is linear)
+  const int row = (tid >> 3) & (BKP - 1), slot = tid & 7, grp = tid / (8 * BKP);
+  const int chunk = SZ == 2 ? (slot ^ (((row >> 1) & 1) << 2)) : slot;
+  const int wrow8 = 8 * (wave % (BKP / 8));                 // first tile row of this wave's instruction
   typedef __attribute__((address_space(3))) void* lds_ptr;
   const auto rsG = __builtin_amdgcn_make_buffer_rsrc((void*)gat, 0, (int)d.in_bytes, 0x00020000);
   const auto rsA = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, (int)rows_bytes, 0x00020000);
-  // rows operand: byte offset of each piece, advanced by one K step per tile; pixels past the end load zeros (the
-  // buffer range check does not see scalar offsets, so the tail is tested here)
-  long pA = (long)s_begin * BKP + rbA;
-  unsigned offA = (unsigned)(((size_t)pA * Cp_r + mcol) * SZ), vA[PPTA];
-  const unsigned a_step_bytes = (unsigned)(BKP * Cp_r * SZ), a_row_bytes = (unsigned)(RSTEPA * Cp_r * SZ);
 
-  // per-piece pixel coordinates of the gather operand, advanced incrementally (no division in the loop)
-  int pn0, pn1, pn2, pn3, ph0, ph1, ph2, ph3, pw0, pw1, pw2, pw3;
-  long pbase = (long)s_begin * BKP + rb;
-  {
-    auto split = [&](long p, int& n_, int& h_, int& w_) {
-      const long nn = p / npix;
-      const int rem = (int)(p - nn * npix);
-      n_ = (int)nn; h_ = rem / Wg; w_ = rem - h_ * Wg;
-    };
-    split(pbase, pn0, ph0, pw0);
-    split(pbase + RSTEP, pn1, ph1, pw1);
-    split(pbase + 2 * RSTEP, pn2, ph2, pw2);
-    split(pbase + 3 * RSTEP, pn3, ph3, pw3);
-  }
-  unsigned vG[4];
-
-#define P2PHD_WG_PREP(I, PN, PH, PW)                                                                         \
-  {                                                                                                          \
-    unsigned off = kOOB;                                                                                     \
-    if (gvalid && pbase + (I) * RSTEP < P) {                                                                 \
-      int hi = PH * sh + dh, wi = PW * sw + dw;                                                              \
-      if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }                           \
-      if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win)                                                        \
-        off = ((unsigned)((PN * Hin + hi) * Win + wi) * (unsigned)Cpi + (unsigned)g_c) * (unsigned)SZ;       \
-    }                                                                                                        \
-    vG[I] = off;                                                                                             \
-    PW += BKP;                                                                                               \
-    while (PW >= Wg) { PW -= Wg; ++PH; }                                                                     \
-    while (PH >= Hg) { PH -= Hg; ++PN; }                                                                     \
-  }
-  auto prepare = [&]() {
+  // gather pieces: column -> (tap, channel), fixed per thread
+  const int T_taps = d.nth * d.ntw;
+  int g_dh[PPT], g_dw[PPT];
+  unsigned g_cB[PPT];
+  bool g_ok[PPT];
 #pragma unroll
-    for (int i = 0; i < PPTA; ++i) vA[i] = (mvalid && pA + RSTEPA * i < P) ? offA + i * a_row_bytes : kOOB;
-    pA += BKP;
-    offA += a_step_bytes;
-    P2PHD_WG_PREP(0, pn0, ph0, pw0)
-    P2PHD_WG_PREP(1, pn1, ph1, pw1)
-    P2PHD_WG_PREP(2, pn2, ph2, pw2)
-    P2PHD_WG_PREP(3, pn3, ph3, pw3)
-    pbase += BKP;
+  for (int j = 0; j < PPT; ++j) {
+    const int kk = j0 + (grp * PPT + j) * CPP + chunk * EPP;
+    const int t = kk / Cpi;
+    g_ok[j] = t < T_taps;
+    const int ta = t / d.ntw, tb = t - ta * d.ntw;
+    g_dh[j] = d.dh0 + ta * d.dh_step; g_dw[j] = d.dw0 + tb * d.dw_step;
+    g_cB[j] = (unsigned)((kk - t * Cpi) * SZ);
+  }
+  const bool same_tap = g_ok[0] && g_ok[PPT - 1] && g_dh[0] == g_dh[PPT - 1] && g_dw[0] == g_dw[PPT - 1] &&
+                        (j0 + (grp * PPT) * CPP + chunk * EPP) / Cpi == (j0 + (grp * PPT + PPT - 1) * CPP + chunk * EPP) / Cpi;
+  // rows-operand pieces
+  unsigned a_cB[PPTA];
+  bool a_ok[PPTA];
+  int rowA = row;
+  int waveA8 = wrow8;
+  if constexpr (kNarrowA) {
+    const int tidA = tid & 255;
+    rowA = tidA >> 2;
+    const int mcol = m0 + (tidA & 3) * EPP;
+    a_ok[0] = mcol < Cp_r; a_cB[0] = (unsigned)(mcol * SZ);
+    waveA8 = 16 * (wave & 3);
+  } else {
+#pragma unroll
+    for (int j = 0; j < PPTA; ++j) {
+      const int panel = NPA >= GROUPS ? grp * PPTA + j : 0;
+      const int mcol = m0 + panel * CPP + chunk * EPP;
+      a_ok[j] = mcol < Cp_r; a_cB[j] = (unsigned)(mcol * SZ);
+    }
+  }
+  const unsigned CpiB = (unsigned)(Cpi * SZ), CprB = (unsigned)(Cp_r * SZ);
+
+  // pixel of this thread's row, advanced by BKP per K step
+  long pcur = (long)s_begin * BKP + row;
+  int pn, ph, pw;
+  {
+    const long nn = pcur / npix;
+    const int rem = (int)(pcur - nn * npix);
+    pn = (int)nn; ph = rem / Wg; pw = rem - ph * Wg;
+  }
+  long pA = (long)s_begin * BKP + rowA;
+  unsigned vG[PPT], vA[PPTA];
+
+  auto pix_off = [&](int dh, int dw) -> unsigned {
+    int hi = ph * sh + dh, wi = pw * sw + dw;
+    if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
+    return ((unsigned)hi < (unsigned)Hin && (unsigned)wi < (unsigned)Win) ? (unsigned)((pn * Hin + hi) * Win + wi) * CpiB : kOOB;
   };
-#undef P2PHD_WG_PREP
-  // piece j of tile `tile` (index relative to s_begin): 0..3 gather rows, 4.. rows-operand rows
-  auto issue_piece = [&](int slot_, int tile, int j) {
-    char* A = smem + slot_ * STAGE;
-    if (j < 4) {
-      char* G = A + TILEA + (size_t)((64 / CPR) * wave) * ROWB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)(G + j * RSTEP * ROWB), 16, (int)vG[j], 0, 0, 0);
+  auto prepare = [&]() {
+    if (pcur < P) {
+      if (same_tap) {
+        const unsigned o = pix_off(g_dh[0], g_dw[0]);
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) vG[j] = o == kOOB ? kOOB : o + g_cB[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const unsigned o = g_ok[j] ? pix_off(g_dh[j], g_dw[j]) : kOOB;
+          vG[j] = o == kOOB ? kOOB : o + g_cB[j];
+        }
+      }
     } else {
-      char* Aw = A + (size_t)((64 / CPRA) * waveA) * ROWA;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(Aw + (j - 4) * RSTEPA * ROWA), 16, (int)vA[j - 4], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < PPT; ++j) vG[j] = kOOB;
+    }
+#pragma unroll
+    for (int j = 0; j < PPTA; ++j) vA[j] = (a_ok[j] && pA < P) ? (unsigned)pA * CprB + a_cB[j] : kOOB;
+    pcur += BKP; pA += BKP;
+    pw += BKP;
+    while (pw >= Wg) { pw -= Wg; ++ph; }
+    while (ph >= Hg) { ph -= Hg; ++pn; }
+  };
+  // piece j of a tile: 0..3 gather panels, 4.. rows-operand panels
+  auto issue_piece = [&](int slot_, int j) {
+    char* A = smem + slot_ * STAGE;
+    if (j < PPT) {
+      char* G = A + TILEA + (grp * PPT + j) * PANEL + wrow8 * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)G, 16, (int)vG[j], 0, 0, 0);
+    } else {
+      char* Aw;
+      if constexpr (kNarrowA) Aw = A + waveA8 * 64;
+      else Aw = A + (NPA >= GROUPS ? grp * PPTA + (j - PPT) : 0) * PANEL + waveA8 * 128;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)Aw, 16, (int)vA[j - PPT], 0, 0, 0);
     }
   };
 
@@ -499,24 +519,25 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 
   const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   // transposing LDS read: 16-lane group g reads a 4-pixel x 16-channel block, lane i gets channel i; lane 4q+p of the
-  // group supplies row (8h + q), logical 8-byte column unit u = 4*(g&1) + p  (u>>1 = 16-B chunk)
+  // group supplies row (8h + q), 8-byte column unit u = 4*(g&1) + p of the 32-column block (u>>1 = 16-B chunk)
   const int g16 = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, pq = i16 & 3, hh = g16 >> 1;
   const int u8 = 4 * (g16 & 1) + pq;
-  const int swz = q4 << 2;                                  // (row & 3) << 2 with row = 16 sub + 8 h + q (+4)
-  const int swzA = TM == 128 ? swz : 0;
+  const int swzq = ((q4 >> 1) & 1) << 2;
+  constexpr int RPA = kNarrowA ? 64 : 128;                  // row pitch of the rows-operand tile
   unsigned ta_off[MI], tg_off[NI];                          // byte offsets (within a stage) of the sub = 0 reads
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
-    const int ca = (wm * (MI * 32) + i * 32) / 8 + (u8 >> 1);
-    ta_off[i] = (unsigned)((8 * hh + q4) * ROWA + ((ca ^ swzA) << 4) + 8 * (u8 & 1));
+    const int mb = wm * (MI * 32) + i * 32;
+    if constexpr (kNarrowA) ta_off[i] = (unsigned)((8 * hh + q4) * 64 + ((u8 >> 1) << 4) + 8 * (u8 & 1));
+    else ta_off[i] = (unsigned)((mb / CPP) * PANEL + (8 * hh + q4) * 128 + (((((mb % CPP) >> 3) + (u8 >> 1)) ^ swzq) << 4) + 8 * (u8 & 1));
   }
 #pragma unroll
   for (int j = 0; j < NI; ++j) {
-    const int cg = (wn * (NI * 32) + j * 32) / 8 + (u8 >> 1);
-    tg_off[j] = (unsigned)(TILEA + (8 * hh + q4) * ROWB + ((cg ^ swz) << 4) + 8 * (u8 & 1));
+    const int nb = wn * (NI * 32) + j * 32;
+    tg_off[j] = (unsigned)(TILEA + (nb / CPP) * PANEL + (8 * hh + q4) * 128 + (((((nb % CPP) >> 3) + (u8 >> 1)) ^ swzq) << 4) + 8 * (u8 & 1));
   }
 
-  auto compute = [&](int slot_, bool pf, int pf_slot, int pf_tile) {
+  auto compute = [&](int slot_, bool pf, int pf_slot) {
     if (pf) prepare();
     if constexpr (SZ == 2) {
       const unsigned so = sbase + (unsigned)(slot_ * STAGE);
@@ -524,15 +545,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       auto read_frags = [&](int sub, int buf) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-          const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * ROWA);
+          const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * RPA);
           asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][0]) : "v"(ad));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * ROWA));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * RPA));
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * ROWB);
+          const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * 128);
           asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][0]) : "v"(ad));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * ROWB));
+          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * 128));
         }
       };
       read_frags(0, 0);
@@ -541,11 +562,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         const int buf = sub & 1;
         if (pf) {
 #pragma unroll
-          for (int j = sub; j < NLOADS; j += BKP / 16) issue_piece(pf_slot, pf_tile, j);
+          for (int j = sub; j < NLOADS; j += BKP / 16) issue_piece(pf_slot, j);
         }
         if (sub + 1 < BKP / 16) {
           read_frags(sub + 1, buf ^ 1);
-          if constexpr (MI + NI == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          if constexpr (MI + NI == 6) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
+          else if constexpr (MI + NI == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
           else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         } else {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -568,7 +590,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       // f32 (parity runs): plain LDS reads; hipcc drains the DMA queue in front of them, which is correct, just slower
       if (pf) {
 #pragma unroll
-        for (int j = 0; j < NLOADS; ++j) issue_piece(pf_slot, pf_tile, j);
+        for (int j = 0; j < NLOADS; ++j) issue_piece(pf_slot, j);
       }
       const char* A = smem + slot_ * STAGE;
       const char* G = A + TILEA;
@@ -578,9 +600,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         const int prow = 2 * s2 + lh;
         float af[MI], gf[NI];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float*>(A + prow * ROWA + (wm * (MI * 32) + i * 32 + lr) * 4);
+        for (int i = 0; i < MI; ++i) {
+          const int col = wm * (MI * 32) + i * 32 + lr;
+          af[i] = *reinterpret_cast<const float*>(A + (col / CPP) * PANEL + prow * 128 + (col % CPP) * 4);
+        }
 #pragma unroll
-        for (int j = 0; j < NI; ++j) gf[j] = *reinterpret_cast<const float*>(G + prow * ROWB + (wn * (NI * 32) + j * 32 + lr) * 4);
+        for (int j = 0; j < NI; ++j) {
+          const int col = wn * (NI * 32) + j * 32 + lr;
+          gf[j] = *reinterpret_cast<const float*>(G + (col / CPP) * PANEL + prow * 128 + (col % CPP) * 4);
+        }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -596,20 +624,21 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     if (t < nsteps) {
       prepare();
 #pragma unroll
-      for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
+      for (int j = 0; j < NLOADS; ++j) issue_piece(t, j);
     }
   }
   int cur = 0, nxt = D;
   for (int s = 0; s < nsteps; ++s) {
-    if (s + 1 < nsteps) {
+    if (D >= 2 && s + 1 < nsteps) {
       if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else if constexpr (NLOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    compute(cur, s + D < nsteps, nxt, s + D);
+    compute(cur, s + D < nsteps, nxt);
     cur = cur == NSTAGE - 1 ? 0 : cur + 1;
     nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
   }
@@ -624,8 +653,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       if (col >= KK) continue;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int row = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        slab[(size_t)row * KK + col] = acc[i][j][e];
+        const int row_o = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        slab[(size_t)row_o * KK + col] = acc[i][j][e];
       }
     }
 }
@@ -830,7 +859,8 @@ template <typename T, int TM>
 void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* dwp, int Cp_r, int mrows, int sps, int splits,
                       long slab_elems, unsigned rows_bytes, hipStream_t st) {
   constexpr int bkp = sizeof(T) == 2 ? 64 : 32;
-  constexpr int lds = 3 * bkp * (256 + TM) * (int)sizeof(T);
+  constexpr int tilea = (TM == 32 && sizeof(T) == 2) ? bkp * 64 : (TM * (int)sizeof(T) / 128 > 0 ? TM * (int)sizeof(T) / 128 : 1) * bkp * 128;
+  constexpr int lds = (TM == 256 ? 2 : 3) * (256 * (int)sizeof(T) / 128 * bkp * 128 + tilea);
   auto kern = wgrad_kernel<T, TM>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   dim3 grid((unsigned)((d.KK + 255) / 256), (unsigned)(mrows / TM), (unsigned)splits);
@@ -842,8 +872,11 @@ void wgrad_split_plan(const GDesc& d, int dtype, int M_rows, int M_rows_pad, int
   const long P = (long)d.N * d.Hg * d.Wg;
   const int bkp = dtype == P2PHD_BF16 ? 64 : 32;
   const int total_steps = (int)std::max<long>(1, (P + bkp - 1) / bkp);
-  *tm = M_rows <= 32 ? 32 : 128;                              // narrow row tile for folded 2-channel layers
-  *mrows = *tm == 32 ? 32 : M_rows_pad;
+  // row tile: 32 for folded 2-channel layers, 256 (wave tile 128 x 64: twice the MFMA work per LDS-DMA piece) when
+  // the output rows fill it, else 128
+  *tm = M_rows <= 32 ? 32 : ((M_rows % 256 == 0 || M_rows >= 1024) ? 256 : 128);
+  if (g_opt_wgrad_tm == 128 && *tm == 256) *tm = 128;
+  *mrows = *tm == 32 ? 32 : round_up(M_rows_pad, *tm);
   const int tiles = (*mrows / *tm) * ((d.KK + 255) / 256);
   // split until the grid covers the chip ~2x (8-wave workgroups, one per CU), keeping >= 8 steps per split and the
   // slab workspace under 256 MiB
@@ -877,9 +910,11 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
     splits = 1;
   } else if (dtype == P2PHD_BF16) {
     if (tm == 32) launch_wgrad_cfg<bf16_t, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
+    else if (tm == 256) launch_wgrad_cfg<bf16_t, 256>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
     else launch_wgrad_cfg<bf16_t, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
   } else if (dtype == P2PHD_F32) {
     if (tm == 32) launch_wgrad_cfg<float, 32>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
+    else if (tm == 256) launch_wgrad_cfg<float, 256>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
     else launch_wgrad_cfg<float, 128>(d, rows, gat, dwp, Cp_r, mrows, sps, splits, slab, (unsigned)rbytes, st);
   } else {
     set_error("wgrad: unsupported dtype %d", dtype);

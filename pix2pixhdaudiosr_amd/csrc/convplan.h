@@ -35,6 +35,7 @@ inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
 
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;
+extern int g_opt_wgrad_tm;
 
 inline int cpitch(int c) { return (c + 7) & ~7; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -28,6 +28,8 @@ CASES = [
     ("c4_s1_to1", 32, 1, 4, 1, 2, 0, False, 0, False, 0, (2, 6, 5), False),               # D head
     ("wide_k200_c136", 136, 200, 3, 1, 1, 1, False, 0, True, 3, (1, 12, 12), False),      # >1 N tile, K not /64
     ("big_m_tiles", 8, 8, 3, 1, 1, 0, False, 0, True, 3, (2, 40, 33), False),             # several M tiles + tail
+    ("wgrad_rows256", 72, 256, 3, 1, 1, 1, False, 0, True, 3, (2, 10, 9), False),         # 256-row weight-gradient tile
+    ("ct_wgrad_rows256", 256, 40, 3, 2, 1, 0, True, 1, True, 3, (1, 6, 7), False),        # same, ConvTranspose (rows = x)
     ("kfold_norm_k3", 8, 3, 7, 1, 3, 1, False, 0, True, 3, (2, 14, 19), False),           # output fold + IN statistics
     ("kfold_c4_k4_zero", 4, 4, 3, 1, 1, 0, False, 0, False, 1, (2, 9, 11), False),        # both tiny: output fold, zero pad
     ("cfold_c3_zero", 3, 24, 5, 1, 2, 0, False, 0, True, 3, (1, 11, 13), False),          # input fold, zero pad
