@@ -27,6 +27,7 @@
 // gfx950 transposing read ds_read_b64_tr_b16, so no transposed copy of the activations is made.
 #include "common.h"
 #include "convplan.h"
+#include <cmath>
 
 namespace {
 
@@ -811,21 +812,30 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // 256-row tiles (8 waves, 3-slot ring) halve the weight traffic per FLOP: used when a sample has enough pixels to
   // fill them, the grid still covers the chip, and ring + gather table fit the 160 KiB of LDS
   d.flat_m = stats == nullptr && (npix % 256 != 0);          // no InstanceNorm sums wanted: tiles may straddle samples
-  const long wg256 = (d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N) * ((k + bn - 1) / bn);
-  const bool fits = bn >= 64 && 3 * (256 + bn) * kRowBytes + taps * 256 * 4 + 16 <= 160 * 1024;
-  bool big = fits && (d.flat_m ? (long)d.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048))) && wg256 >= 192;
-  if (p2phd::g_opt_gconv_bm == 128) big = false;
-  if (p2phd::g_opt_gconv_bm == 256) big = fits;
+  const long mt256 = d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N;
+  const long tabb = (long)taps * 256 * 4 + 16;
+  const long kLds = 160 * 1024;
+  const bool enough_px = d.flat_m ? (long)d.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048));
   // 256 x 256 tiles (8 waves of 128 x 64, 2-slot ring): twice the MFMA work per LDS-DMA piece; for wide layers whose
-  // grid still fills most of the chip
-  const long wg256x256 = (d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N) * ((k + 255) / 256);
-  bool huge = big && k >= 256 && (k % 256 == 0 || k >= 1024) && wg256x256 >= 160 &&
-              2 * 512 * kRowBytes + taps * 256 * 4 + 16 <= 160 * 1024 && 256 * (256 * (int)sizeof(T) + 16) + taps * 256 * 4 + 16 <= 160 * 1024;
-  if (p2phd::g_opt_gconv_bm == 512) huge = fits && k > 128 && sizeof(T) == 2;
-  if (p2phd::g_opt_gconv_bm != 0 && p2phd::g_opt_gconv_bm != 512) huge = false;
+  // grid still fills most of the chip.  256 x {128,64}: 3-slot ring when it fits beside the gather table, else 2-slot.
+  const bool fits_huge = sizeof(T) == 2 && 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
+  bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
+  const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
+  const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(T) + 16) + tabb <= kLds;
+  bool big = (fits3 || fits2) && enough_px && mt256 * ((k + bn - 1) / bn) >= 192;
+  const int force = p2phd::g_opt_gconv_bm;
+  if (force == 128) { big = false; huge = false; }
+  if (force == 256) { big = fits3 || fits2; huge = false; }
+  if (force == 512) { huge = fits_huge && k > 128; }
   if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st);
-  if (big && bn == 128) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
-  if (big && bn == 64) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st);
+  if (big && bn == 128) {
+    if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
+    return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
+  }
+  if (big && bn == 64) {
+    if (fits3) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st);
+    return launch_gconv_cfg<T, 256, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st);
+  }
   if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
   if (bn == 64) return launch_gconv_cfg<T, 128, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st);
   return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st);
@@ -878,12 +888,20 @@ void wgrad_split_plan(const GDesc& d, int dtype, int M_rows, int M_rows_pad, int
   if (g_opt_wgrad_tm == 128 && *tm == 256) *tm = 128;
   *mrows = *tm == 32 ? 32 : round_up(M_rows_pad, *tm);
   const int tiles = (*mrows / *tm) * ((d.KK + 255) / 256);
-  // split until the grid covers the chip ~2x (8-wave workgroups, one per CU), keeping >= 8 steps per split and the
-  // slab workspace under 256 MiB
-  int sp = 1;
-  const size_t slab_bytes = (size_t)*mrows * d.KK * sizeof(float);
-  while (tiles * sp < 512 && total_steps / (sp * 2) >= 8 && slab_bytes * (sp * 2) <= (256u << 20)) sp *= 2;
-  *sps = (total_steps + sp - 1) / sp;
+  // Split of the pixel reduction over blockIdx.z: one 8-wave workgroup per CU, so the grid runs in
+  // ceil(tiles * sp / 256) rounds of ceil(total_steps / sp) K steps; every extra split costs one more slab to write
+  // and to sum.  Pick the cheapest under a 256 MiB workspace.
+  const double t_step = *tm == 256 ? 0.9e-6 : (*tm == 128 ? 0.5e-6 : 0.25e-6);
+  const double slab_bytes = (double)*mrows * d.KK * sizeof(float);
+  int best = 1;
+  double best_cost = 1e30;
+  for (int sp = 1; sp <= 512; ++sp) {
+    if (sp > 1 && (total_steps / sp < 4 || slab_bytes * sp > (double)(256u << 20))) break;
+    const double rounds = std::ceil((double)tiles * sp / 256.0);
+    const double cost = rounds * std::ceil((double)total_steps / sp) * t_step + sp * slab_bytes * 2.0 / 4.0e12 + 2e-6;
+    if (cost < best_cost) { best_cost = cost; best = sp; }
+  }
+  *sps = (total_steps + best - 1) / best;
   *splits = (total_steps + *sps - 1) / *sps;
 }
 
