@@ -30,7 +30,29 @@ __device__ __forceinline__ float act_slope(float v, int act) {   // derivative a
   return 1.f;
 }
 
-constexpr int kMaxCp = 2048;   // channels staged per block (mean / rstd tables)
+constexpr int kMaxCp = 4096;   // bounds the LDS partial-sum tables of the backward kernels
+
+// All three InstanceNorm kernels walk the [HW][Cp] plane of one sample in 16-byte pieces with a grid stride that the
+// host makes a multiple of the pieces per pixel (cpr = Cp / EPP).  A thread therefore stays on ONE group of EPP
+// channels for its whole life: mean / rstd (and the backward means) of those channels are computed once into
+// registers straight from the statistics buffers -- no per-block table, no LDS in the streaming loop -- and the loads
+// of UN pieces are issued before any of them is used.
+template <typename T>
+struct ChanConsts {
+  static constexpr int EPP = Elem<T>::EPP;
+  float mean[EPP], rstd[EPP];
+  __device__ __forceinline__ void load(const float* __restrict__ stats, int n, int Cp, int C, int pc, float inv, float eps) {
+    const float4* s4 = reinterpret_cast<const float4*>(stats + 2 * ((size_t)n * Cp + pc * EPP));
+#pragma unroll
+    for (int k = 0; k < EPP; k += 2) {
+      const float4 v = s4[k >> 1];                               // (sum, sumsq) of two channels
+      const float m0 = v.x * inv, m1 = v.z * inv;
+      mean[k] = m0; mean[k + 1] = m1;
+      rstd[k] = (pc * EPP + k < C) ? rsqrtf(fmaxf(v.y * inv - m0 * m0, 0.f) + eps) : 0.f;
+      rstd[k + 1] = (pc * EPP + k + 1 < C) ? rsqrtf(fmaxf(v.w * inv - m1 * m1, 0.f) + eps) : 0.f;
+    }
+  }
+};
 
 // ---- forward: out = act((y - mean) * rstd) + residual --------------------------------------------
 template <typename T>
@@ -38,42 +60,41 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
                                                          const T* __restrict__ residual, T* __restrict__ out, long HW,
                                                          int C, int Cp, float eps, int act) {
   constexpr int EPP = Elem<T>::EPP;
-  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp];
+  constexpr int UN = 4;
   const int n = blockIdx.y;
-  const float inv = 1.f / (float)HW;
-  for (int c = threadIdx.x; c < Cp; c += 256) {
-    float m = 0.f, r = 0.f;
-    if (c < C) {
-      const float s1 = stats[2 * ((size_t)n * Cp + c)], s2 = stats[2 * ((size_t)n * Cp + c) + 1];
-      m = s1 * inv;
-      const float var = fmaxf(s2 * inv - m * m, 0.f);
-      r = rsqrtf(var + eps);
-    }
-    s_mean[c] = m; s_rstd[c] = r;
-  }
-  __syncthreads();
   const int cpr = Cp / EPP;
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int pc = (int)(e % cpr);
-    const size_t o = base + (size_t)e * EPP;
-    const uint4 v = *reinterpret_cast<const uint4*>(y + o);
-    const T* vv = reinterpret_cast<const T*>(&v);
-    uint4 rv = make_uint4(0, 0, 0, 0);
-    if (residual != nullptr) rv = *reinterpret_cast<const uint4*>(residual + o);
-    const T* rr = reinterpret_cast<const T*>(&rv);
-    uint4 ov;
-    T* oo = reinterpret_cast<T*>(&ov);
+  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  ChanConsts<T> cc;
+  cc.load(stats, n, Cp, C, pc, 1.f / (float)HW, eps);
+  const long stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
+    uint4 yv[UN], rv[UN];
 #pragma unroll
-    for (int k = 0; k < EPP; ++k) {
-      const int c = pc * EPP + k;
-      float f = (to_f(vv[k]) - s_mean[c]) * s_rstd[c];
-      f = act_fwd(f, act);
-      if (residual != nullptr) f += to_f(rr[k]);
-      oo[k] = from_f<T>(c < C ? f : 0.f);
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) {
+        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
+        if (residual != nullptr) rv[u] = *reinterpret_cast<const uint4*>(residual + base + (size_t)e * EPP);
+      }
     }
-    *reinterpret_cast<uint4*>(out + o) = ov;
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e >= total) break;
+      const T* vv = reinterpret_cast<const T*>(&yv[u]);
+      const T* rr = reinterpret_cast<const T*>(&rv[u]);
+      uint4 ov;
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        float f = act_fwd((to_f(vv[k]) - cc.mean[k]) * cc.rstd[k], act);
+        if (residual != nullptr) f += to_f(rr[k]);
+        oo[k] = from_f<T>(pc * EPP + k < C ? f : 0.f);
+      }
+      *reinterpret_cast<uint4*>(out + base + (size_t)e * EPP) = ov;
+    }
   }
 }
 
@@ -81,36 +102,41 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                 const float* __restrict__ stats, float* __restrict__ bstats,
-                                                                long HW, int C, int Cp, float eps, int act, int cpg) {
+                                                                long HW, int C, int Cp, float eps, int act) {
   constexpr int EPP = Elem<T>::EPP;
-  __shared__ float red[256 * 8 * 2];
-  const int n = blockIdx.z;
+  constexpr int UN = 4;
+  extern __shared__ float s_acc[];                              // [Cp][2] block partial sums
+  for (int c = threadIdx.x; c < 2 * Cp; c += 256) s_acc[c] = 0.f;
+  __syncthreads();
+  const int n = blockIdx.y;
   const int cpr = Cp / EPP;
-  const int pl = threadIdx.x % cpg, rl = threadIdx.x / cpg, R = 256 / cpg;
-  const int pc = blockIdx.y * cpg + pl;
-  const bool valid = pc < cpr && rl < R;
-  float mean[EPP], rstd[EPP], a1[EPP], a2[EPP];
-  const float inv = 1.f / (float)HW;
+  const long total = HW * cpr;
+  const size_t base = (size_t)n * HW * Cp;
+  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  ChanConsts<T> cc;
+  cc.load(stats, n, Cp, C, pc, 1.f / (float)HW, eps);
+  float a1[EPP], a2[EPP];
 #pragma unroll
-  for (int k = 0; k < EPP; ++k) {
-    a1[k] = a2[k] = 0.f; mean[k] = 0.f; rstd[k] = 0.f;
-    const int c = pc * EPP + k;
-    if (valid && c < C) {
-      const float s1 = stats[2 * ((size_t)n * Cp + c)], s2 = stats[2 * ((size_t)n * Cp + c) + 1];
-      mean[k] = s1 * inv;
-      rstd[k] = rsqrtf(fmaxf(s2 * inv - mean[k] * mean[k], 0.f) + eps);
+  for (int k = 0; k < EPP; ++k) a1[k] = a2[k] = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
+    uint4 gv[UN], yv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) {
+        gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
+        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
+      }
     }
-  }
-  if (valid) {
-    const size_t base = (size_t)n * HW * Cp + (size_t)pc * EPP;
-    for (long p = (long)blockIdx.x * R + rl; p < HW; p += (long)gridDim.x * R) {
-      const uint4 gv = *reinterpret_cast<const uint4*>(g + base + (size_t)p * Cp);
-      const uint4 yv = *reinterpret_cast<const uint4*>(y + base + (size_t)p * Cp);
-      const T* gg = reinterpret_cast<const T*>(&gv);
-      const T* yy = reinterpret_cast<const T*>(&yv);
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (e0 + u * stride >= total) break;
+      const T* gg = reinterpret_cast<const T*>(&gv[u]);
+      const T* yy = reinterpret_cast<const T*>(&yv[u]);
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
-        const float yh = (to_f(yy[k]) - mean[k]) * rstd[k];
+        const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
         const float gp = to_f(gg[k]) * act_slope(yh, act);
         a1[k] += gp; a2[k] += gp * yh;
       }
@@ -118,24 +144,11 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
   }
 #pragma unroll
   for (int k = 0; k < EPP; ++k) {
-    red[(threadIdx.x * 8 + k) * 2] = a1[k];
-    red[(threadIdx.x * 8 + k) * 2 + 1] = a2[k];
+    atomicAdd(&s_acc[2 * (pc * EPP + k)], a1[k]);               // LDS atomics: one pair per thread and channel
+    atomicAdd(&s_acc[2 * (pc * EPP + k) + 1], a2[k]);
   }
   __syncthreads();
-  if (valid && rl == 0) {
-#pragma unroll
-    for (int k = 0; k < EPP; ++k) {
-      const int c = pc * EPP + k;
-      if (c >= C) continue;
-      float t1 = 0.f, t2 = 0.f;
-      for (int r = 0; r < R; ++r) {
-        t1 += red[((r * cpg + pl) * 8 + k) * 2];
-        t2 += red[((r * cpg + pl) * 8 + k) * 2 + 1];
-      }
-      atomicAdd(&bstats[2 * ((size_t)n * Cp + c)], t1);
-      atomicAdd(&bstats[2 * ((size_t)n * Cp + c) + 1], t2);
-    }
-  }
+  for (int c = threadIdx.x; c < 2 * C; c += 256) atomicAdd(&bstats[2 * (size_t)n * Cp + c], s_acc[c]);
 }
 
 // ---- backward pass 2: dy = rstd * (g' - mean(g') - yhat * mean(g' yhat)) ---------------------------
@@ -145,46 +158,58 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
                                                                T* __restrict__ dy, long HW, int C, int Cp, float eps, int act,
                                                                float* __restrict__ db) {
   constexpr int EPP = Elem<T>::EPP;
-  __shared__ float s_mean[kMaxCp], s_rstd[kMaxCp], s_m1[kMaxCp], s_m2[kMaxCp], s_db[kMaxCp];
+  constexpr int UN = 4;
+  extern __shared__ float s_db[];                               // [Cp] bias-gradient partials (only when db != NULL)
+  if (db != nullptr) {
+    for (int c = threadIdx.x; c < Cp; c += 256) s_db[c] = 0.f;
+    __syncthreads();
+  }
   const int n = blockIdx.y;
   const float inv = 1.f / (float)HW;
-  for (int c = threadIdx.x; c < Cp; c += 256) {
-    float m = 0.f, r = 0.f, m1 = 0.f, m2 = 0.f;
-    if (c < C) {
-      const size_t i = 2 * ((size_t)n * Cp + c);
-      m = stats[i] * inv;
-      r = rsqrtf(fmaxf(stats[i + 1] * inv - m * m, 0.f) + eps);
-      m1 = bstats[i] * inv; m2 = bstats[i + 1] * inv;
-    }
-    s_mean[c] = m; s_rstd[c] = r; s_m1[c] = m1; s_m2[c] = m2; s_db[c] = 0.f;
-  }
-  __syncthreads();
   const int cpr = Cp / EPP;
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
-  // The host picks gridDim.x so that the stride (gridDim.x * 256) is a multiple of cpr: every thread then stays on
-  // one group of EPP channels and can keep the bias-gradient partial sums (column sums of dy) in registers.
-  float bsum[EPP];
-#pragma unroll
-  for (int k = 0; k < EPP; ++k) bsum[k] = 0.f;
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const size_t o = base + (size_t)e * EPP;
-    const uint4 gv = *reinterpret_cast<const uint4*>(g + o);
-    const uint4 yv = *reinterpret_cast<const uint4*>(y + o);
-    const T* gg = reinterpret_cast<const T*>(&gv);
-    const T* yy = reinterpret_cast<const T*>(&yv);
-    uint4 ov;
-    T* oo = reinterpret_cast<T*>(&ov);
+  ChanConsts<T> cc;
+  cc.load(stats, n, Cp, C, pc, inv, eps);
+  float m1[EPP], m2[EPP], bsum[EPP];
+  {
+    const float4* b4 = reinterpret_cast<const float4*>(bstats + 2 * ((size_t)n * Cp + pc * EPP));
 #pragma unroll
-    for (int k = 0; k < EPP; ++k) {
-      const int c = pc * EPP + k;
-      const float yh = (to_f(yy[k]) - s_mean[c]) * s_rstd[c];
-      const float gp = to_f(gg[k]) * act_slope(yh, act);
-      oo[k] = from_f<T>(c < C ? s_rstd[c] * (gp - s_m1[c] - yh * s_m2[c]) : 0.f);
-      bsum[k] += to_f(oo[k]);                                   // what the next kernels read, i.e. the rounded dy
+    for (int k = 0; k < EPP; k += 2) {
+      const float4 v = b4[k >> 1];
+      m1[k] = v.x * inv; m2[k] = v.y * inv; m1[k + 1] = v.z * inv; m2[k + 1] = v.w * inv;
+      bsum[k] = bsum[k + 1] = 0.f;
     }
-    *reinterpret_cast<uint4*>(dy + o) = ov;
+  }
+  const long stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
+    uint4 gv[UN], yv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) {
+        gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
+        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e >= total) break;
+      const T* gg = reinterpret_cast<const T*>(&gv[u]);
+      const T* yy = reinterpret_cast<const T*>(&yv[u]);
+      uint4 ov;
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
+        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        oo[k] = from_f<T>(cc.rstd[k] * (gp - m1[k] - yh * m2[k]));
+        bsum[k] += to_f(oo[k]);                                 // what the next kernels read, i.e. the rounded dy
+      }
+      *reinterpret_cast<uint4*>(dy + base + (size_t)e * EPP) = ov;
+    }
   }
   if (db != nullptr) {
 #pragma unroll
@@ -332,6 +357,20 @@ inline int grid_for(long work, int cap = 8192) { return (int)std::max<long>(1, s
 
 }  // namespace
 
+namespace {
+// grid.x for the channel-stationary kernels: stride gx * 256 must be a multiple of cpr; few fat blocks so that the
+// per-thread constant setup and the end-of-block atomics are amortised
+int stationary_grid(long HW, int cpr, int N) {
+  int gcd = cpr, b = 256;
+  while (b) { const int t = gcd % b; gcd = b; b = t; }
+  const int unit = cpr / gcd;
+  long want = (HW * cpr + 256 * 8 - 1) / (256 * 8);            // >= 8 pieces per thread
+  want = std::min<long>(want, std::max(1, 2048 / std::max(N, 1)));
+  int gx = (int)std::max<long>(unit, want / unit * unit);
+  return gx;
+}
+}  // namespace
+
 extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
                                       int N, int64_t HW, int C, float eps, int act, void* stream) {
   const int Cp = (C + 7) & ~7;
@@ -339,7 +378,7 @@ extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* sta
   if (N == 0 || HW == 0) return P2PHD_OK;
   P2PHD_REQUIRE(y && stats && out, "instnorm_act_fwd: null pointer");
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
-  dim3 grid(grid_for(HW * (Cp / epp), 2048), N);
+  dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, stats, (const bf16_t*)residual, (bf16_t*)out, (long)HW, C, Cp, eps, act),
@@ -356,31 +395,17 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
   P2PHD_REQUIRE(g && y && stats && bstats && dy, "instnorm_act_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
   (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
+  if (db != nullptr) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
-  const int cpr = Cp / epp;
-  int cpg = 1;
-  while (cpg * 2 <= cpr && cpg * 2 <= 64) cpg *= 2;            // power of two so 256 % cpg == 0
-  const int R = 256 / cpg;
-  const int ygroups = (cpr + cpg - 1) / cpg;
-  const int xblocks = (int)std::max<long>(1, std::min<long>((HW + R * 16 - 1) / (R * 16), 1024));
-  dim3 rgrid(xblocks, ygroups, N);
+  dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act, cpg),
-             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act, cpg),
+             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act),
+             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act),
              "instnorm_act_bwd");
   if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
-  // stride (gx * 256) must be a multiple of cpr so a thread keeps its channel group: gx = multiple of cpr / gcd(cpr, 256)
-  int gcd = cpr, b256 = 256;
-  while (b256) { const int t = gcd % b256; gcd = b256; b256 = t; }
-  const int unit = cpr / gcd;
-  // few fat blocks (<= ~2048 over all samples): each ends with one global atomic per channel for the bias gradient
-  int gx = std::min(grid_for(HW * cpr, 2048), std::max(1, 2048 / std::max(N, 1)));
-  gx = std::max(unit, gx / unit * unit);
-  dim3 grid(gx, N);
-  if (db != nullptr) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act, db),
-             hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act, db),
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act, db),
+             hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act, db),
              "instnorm_act_bwd");
   return p2phd::check_launch("instnorm_act_bwd(apply)");
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Run one optimisation step of every BASELINE.json configuration that fits one GPU (robustness + timing)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import make_opt
+from pix2pixhdaudiosr_amd.models.models import create_model
+
+CONFIGS = {
+    # name: (overrides, batch)
+    "cfg1 ngf32 global nd4 nb9 fp32 B2": (dict(ngf=32, fp16=False), 2),
+    "cfg2 ngf48 global bf16 B32": (dict(), 32),
+    "cfg3 G3L2_48ngf (opt.txt: local nd4 nbg3 nle1 nbl2) fp32 B4": (dict(netG="local", n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=False), 4),
+    "cfg3' (BASELINE wording: local nd3 nb9 nle2 nbl3) bf16 B8": (dict(netG="local", n_downsample_global=3, n_blocks_global=9, n_local_enhancers=2, n_blocks_local=3), 8),
+    "cfg5 n_fft2048 ngf64 local defaults num_D3 bf16 B4": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3), 4),
+}
+
+def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    for name, (ov, B) in CONFIGS.items():
+        if only and only not in name:
+            continue
+        opt = make_opt(B)
+        for k, v in ov.items():
+            setattr(opt, k, v)
+        torch.manual_seed(1234)
+        model = create_model(opt)
+        frames = opt.n_fft // 4
+        T = (frames - 1) * opt.hop_length
+        hr = 0.1 * torch.randn(B, T, device="cuda"); lr = 0.1 * torch.randn(B, T, device="cuda")
+        ld = model.train_step(lr, hr); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 3
+        for _ in range(n):
+            ld = model.train_step(lr, hr)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        vals = {k: round(float(v), 4) for k, v in ld.items()}
+        ok = all(torch.isfinite(p).all() for p in model.parameters())
+        nG = sum(p.numel() for p in model.netG.parameters())
+        print(f"{name}: {dt*1e3:.1f} ms/step, {B*frames/dt:.0f} frames/s, G params {nG}, finite={ok}, losses {vals}", flush=True)
+        del model
+        torch.cuda.empty_cache()
+
+if __name__ == "__main__":
+    main()
