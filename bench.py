@@ -172,11 +172,19 @@ def main():
                        "step_frac_of_bf16_peak": step_flops / (dt / a.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS},
         }
         log(f"timed region done: {ms:.1f} ms/step")
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
+        # from the separate rocprofv3 --pmc passes recorded in profiles/ (same kernel, same shapes, per launch)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_trunk_pmc.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_launch"] if a.batch == 32 else None
+        except Exception:
+            traffic = None
         sec, flops = time_trunk_conv(a.batch)
         log(f"trunk conv {sec * 1e6:.1f} us/launch")
         out["roofline"] = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": None,
-                           "kernel": "gconv_kernel<bf16,BN=128> Conv3x3 768->768 @32x16 (residual trunk)",
+                           "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                           "kernel": "gconv_kernel<bf16> implicit-GEMM Conv3x3 768->768 @32x16 (residual trunk, 18 of 28 generator convs)",
                            "launch_us": sec * 1e6, "flops_per_launch": flops}
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle, batch 2, 4 steps) ...")
