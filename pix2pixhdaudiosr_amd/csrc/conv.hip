@@ -822,7 +822,10 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
   const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
   const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(T) + 16) + tabb <= kLds;
-  bool big = (fits3 || fits2) && enough_px && mt256 * ((k + bn - 1) / bn) >= 192;
+  // short reductions (<= 4 K steps: the folded 2-channel layers, the 4-channel D input) are all prologue and epilogue:
+  // keep the light 128-row kernel there, several of which fit on a CU and overlap each other's fixed costs
+  const bool short_k = d.KK <= 4 * 8 * Elem<T>::EPP;
+  bool big = (fits3 || fits2) && enough_px && !short_k && mt256 * ((k + bn - 1) / bn) >= 192;
   const int force = p2phd::g_opt_gconv_bm;
   if (force == 128) { big = false; huge = false; }
   if (force == 256) { big = fits3 || fits2; huge = false; }

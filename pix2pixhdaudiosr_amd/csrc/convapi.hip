@@ -177,6 +177,9 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
   }
 }
 
+// more than ~128 epilogue adds per (n, channel) address: 128-row tiles x 2 waves along M
+bool separate_stats(int Ho, int Wo) { return ((long)Ho * Wo + 127) / 128 * 2 > 256; }
+
 size_t padded_dx_bytes(const p2phd_conv_desc* c) {
   if (c->pad_mode != 1) return 0;
   return align256((size_t)c->N * (c->H + 2 * c->pad) * (c->W + 2 * c->pad) * cpitch(c->C) * elem_size(c->dtype));
@@ -252,13 +255,20 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
     if (int rc = launch_expand_in(c->dtype, x, workspace, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
     Plan& p = plans[0];
     p.d.act = act;
-    return launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, stats, st);
+    const bool sep = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
+    if (int rc = launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, sep ? nullptr : stats, st)) return rc;
+    if (sep) return launch_plane_stats(c->dtype, y, stats, c->N, (long)Ho * Wo, c->K, st);
+    return P2PHD_OK;
   }
+  // InstanceNorm sums: in the conv epilogue (float atomics, one per wave and channel) unless a sample spans so many
+  // M tiles that thousands of adds would pile onto each (n, channel) address; then a stand-alone pass over y is cheaper
+  const bool sep_stats = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
   for (auto& p : plans) {
     p.d.act = act;
     const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, stats, st)) return rc;
+    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, sep_stats ? nullptr : stats, st)) return rc;
   }
+  if (sep_stats) return launch_plane_stats(c->dtype, y, stats, c->N, (long)Ho * Wo, c->K, st);
   return P2PHD_OK;
 }
 

@@ -50,6 +50,7 @@ int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx
                         hipStream_t st);
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st);
 
+int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st);
 int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,
                      hipStream_t st);
 int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st);

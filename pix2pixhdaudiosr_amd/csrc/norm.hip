@@ -219,6 +219,49 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
   }
 }
 
+// ---- per-(n,c) sum and sum of squares of a plane (InstanceNorm statistics as a stand-alone pass) ----
+// Used instead of the conv-epilogue atomics for layers with many M tiles per sample (48/96-channel layers at
+// 512x256 / 256x128): thousands of float atomics on one address are far slower than one more read of the tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void plane_stats_kernel(const T* __restrict__ y, float* __restrict__ stats, long HW, int C, int Cp) {
+  constexpr int EPP = Elem<T>::EPP;
+  constexpr int UN = 4;
+  extern __shared__ float s_acc[];                              // [Cp][2]
+  for (int c = threadIdx.x; c < 2 * Cp; c += 256) s_acc[c] = 0.f;
+  __syncthreads();
+  const int n = blockIdx.y;
+  const int cpr = Cp / EPP;
+  const long total = HW * cpr;
+  const size_t base = (size_t)n * HW * Cp;
+  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  float a1[EPP], a2[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) a1[k] = a2[k] = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
+    uint4 yv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      if (e < total) yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (e0 + u * stride >= total) break;
+      const T* yy = reinterpret_cast<const T*>(&yv[u]);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) { const float v = to_f(yy[k]); a1[k] += v; a2[k] += v * v; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) {
+    atomicAdd(&s_acc[2 * (pc * EPP + k)], a1[k]);
+    atomicAdd(&s_acc[2 * (pc * EPP + k) + 1], a2[k]);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < 2 * C; c += 256) atomicAdd(&stats[2 * (size_t)n * Cp + c], s_acc[c]);
+}
+
 // ---- activation backward from the saved OUTPUT (conv layers whose activation is fused, no norm) ----
 template <typename T>
 __global__ void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a, T* __restrict__ dx, long n_pieces, int act) {
@@ -370,6 +413,20 @@ int stationary_grid(long HW, int cpr, int N) {
   return gx;
 }
 }  // namespace
+
+namespace p2phd {
+int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st) {
+  const int Cp = (C + 7) & ~7;
+  if (N == 0 || HW == 0) return P2PHD_OK;
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  dim3 grid(stationary_grid(HW, Cp / epp, N), N);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(plane_stats_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)y, stats, HW, C, Cp);
+  else
+    hipLaunchKernelGGL(plane_stats_kernel<float>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const float*)y, stats, HW, C, Cp);
+  return check_launch("plane_stats");
+}
+}  // namespace p2phd
 
 extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
                                       int N, int64_t HW, int C, float eps, int act, void* stream) {

@@ -27,43 +27,50 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // Xe[n,h,wo,(tw*C + c)] = x[n,h,map(wo + tw - pad),c]   (map = reflect or zero), wo in [0,Wo)
+// one thread per output pixel: gathers its S*C values and writes the Cep-channel row as 16-byte pieces
 template <typename T>
-__global__ void expand_in_kernel(const T* __restrict__ x, T* __restrict__ xe, long NH, int W, int Wo, int C, int Cp, int S,
-                                 int pad, int pad_mode, int Cep) {
-  const long total = NH * Wo * Cep;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int ce = (int)(e % Cep);
-    const long r = e / Cep;
-    const int wo = (int)(r % Wo);
-    const long nh = r / Wo;
-    float v = 0.f;
-    if (ce < S * C) {
-      const int tw = ce / C, c = ce - tw * C;
+__global__ __launch_bounds__(256) void expand_in_kernel(const T* __restrict__ x, T* __restrict__ xe, long NH, int W, int Wo, int C, int Cp,
+                                                        int S, int pad, int pad_mode, int Cep) {
+  const long total = NH * Wo;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int wo = (int)(e % Wo);
+    const long nh = e / Wo;
+    alignas(16) T row[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) row[i] = from_f<T>(0.f);
+    for (int tw = 0; tw < S; ++tw) {
       int wi = wo + tw - pad;
       if (pad_mode == 1) wi = reflect_idx(wi, W);
-      if (wi >= 0 && wi < W) v = to_f(x[(nh * W + wi) * Cp + c]);
+      if (wi < 0 || wi >= W) continue;
+      const T* src = x + (nh * W + wi) * Cp;
+      for (int c = 0; c < C; ++c) row[tw * C + c] = src[c];
     }
-    xe[e] = from_f<T>(v);
+    uint4* dst = reinterpret_cast<uint4*>(xe + e * Cep);
+    const uint4* r4 = reinterpret_cast<const uint4*>(row);
+    for (int i = 0; i < Cep * (int)sizeof(T) / 16; ++i) dst[i] = r4[i];
   }
 }
 
-// dyE[n,h,w',(tw*K + k)] = dy[n,h,w'-tw,k] (zero outside [0,Wo)), w' in [0,Wy)
+// dyE[n,h,w',(tw*K + k)] = dy[n,h,w'-tw,k] (zero outside [0,Wo)), w' in [0,Wy); one thread per folded pixel
 template <typename T>
-__global__ void expand_dy_kernel(const T* __restrict__ dy, T* __restrict__ dye, long NH, int Wo, int Wy, int K, int Kp,
-                                 int S, int Cep) {
-  const long total = NH * Wy * Cep;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int ce = (int)(e % Cep);
-    const long r = e / Cep;
-    const int wy = (int)(r % Wy);
-    const long nh = r / Wy;
-    float v = 0.f;
-    if (ce < S * K) {
-      const int tw = ce / K, k = ce - tw * K;
+__global__ __launch_bounds__(256) void expand_dy_kernel(const T* __restrict__ dy, T* __restrict__ dye, long NH, int Wo, int Wy, int K, int Kp,
+                                                        int S, int Cep) {
+  const long total = NH * Wy;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int wy = (int)(e % Wy);
+    const long nh = e / Wy;
+    alignas(16) T row[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) row[i] = from_f<T>(0.f);
+    for (int tw = 0; tw < S; ++tw) {
       const int w = wy - tw;
-      if (w >= 0 && w < Wo) v = to_f(dy[(nh * Wo + w) * Kp + k]);
+      if (w < 0 || w >= Wo) continue;
+      const T* src = dy + (nh * Wo + w) * Kp;
+      for (int k = 0; k < K; ++k) row[tw * K + k] = src[k];
     }
-    dye[e] = from_f<T>(v);
+    uint4* dst = reinterpret_cast<uint4*>(dye + e * Cep);
+    const uint4* r4 = reinterpret_cast<const uint4*>(row);
+    for (int i = 0; i < Cep * (int)sizeof(T) / 16; ++i) dst[i] = r4[i];
   }
 }
 
@@ -121,7 +128,8 @@ int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, in
                      hipStream_t st) {
   const int Cp = cpitch(C), Cep = cpitch(S * C);
   const long NH = (long)N * H;
-  const long total = NH * Wo * Cep;
+  const long total = NH * Wo;
+  P2PHD_REQUIRE(Cep <= 32, "expand_in: folded channel count must be <= 32");
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(expand_in_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)xe, NH, W, Wo, C, Cp, S, pad, pad_mode, Cep);
   else
@@ -132,7 +140,8 @@ int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, in
 int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st) {
   const int Kp = cpitch(K), Cep = cpitch(S * K);
   const long NH = (long)N * Ho;
-  const long total = NH * Wy * Cep;
+  const long total = NH * Wy;
+  P2PHD_REQUIRE(Cep <= 32, "expand_dy: folded channel count must be <= 32");
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(expand_dy_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dye, NH, Wo, Wy, K, Kp, S, Cep);
   else
