@@ -89,7 +89,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   // descriptor fields used in loops live in registers (a by-value struct that is captured by reference ends
   // up in scratch memory)
   const int Cp = d.Cp_in, KK = d.KK, Wg = d.Wg, T_taps = d.nth * d.ntw, npix = d.Hg * d.Wg;
-  const int Cp_out = d.Cp_out, Kout = d.Kout, act = d.act;
+  const int Cp_out = d.Cp_out, Kout = d.Kout, act = d.act, cls_cp = d.cls_cp, n_extent = d.n_extent;
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
@@ -303,7 +303,8 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
 #pragma unroll
   for (int j = 0; j < NR; ++j) {
     const int col = wn * (NR * 32) + j * 32 + lr;
-    const int k = n0 + col;
+    int k = n0 + col;
+    if (cls_cp > 0) k = k < n_extent ? k % cls_cp : Kout;      // merged sub-pixel classes share bias / statistics of channel k
     const float bv = (bias != nullptr && k < Kout) ? bias[k] : 0.f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -332,11 +333,17 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
     int p = p_base + row;
-    const int k = n0 + pc * EPP;
-    if (p >= p_end || k >= Cp_out) continue;
+    int k = n0 + pc * EPP;
+    if (p >= p_end || k >= n_extent) continue;
     int nn = n;
     if (flat) { nn = p / npix; p -= nn * npix; }
-    const int ho = p / Wg, wo = p - ho * Wg;
+    int ho = p / Wg, wo = p - ho * Wg;
+    if (cls_cp > 0) {                                          // class (pi,pj) -> output pixel (2 ho + pi, 2 wo + pj)
+      const int cls = k / cls_cp;
+      k -= cls * cls_cp;
+      ho = 2 * ho + (cls >> 1); wo = 2 * wo + (cls & 1);
+      if (ho >= Hout || wo >= Wout) continue;
+    }
     const size_t opix = ((size_t)nn * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo);
     uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
     if (addend != nullptr) {
@@ -681,6 +688,29 @@ __global__ void pack_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w,
   }
 }
 
+// Packed weights of a merged sub-pixel launch (stride 2, transposed form):
+//   Wp[(cls, k)][(dh, dw)][c] = w(k, c, r, s)  with  r = pi + pad - 2 dh,  s = pj + pad - 2 dw  (0 when outside the kernel)
+template <typename T>
+__global__ void pack_merged_kernel(GDesc d, const float* __restrict__ w, T* __restrict__ wp, int rows_pad, int K, int C, int R, int S,
+                                   int pad, long s_k, long s_c) {
+  const long total = (long)rows_pad * d.KK;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(e / d.KK);
+    const int kk = (int)(e - (long)row * d.KK);
+    const int t = kk / d.Cp_in, c = kk - t * d.Cp_in;
+    float v = 0.f;
+    if (row < 4 * d.cls_cp && t < d.nth * d.ntw && c < C) {
+      const int cls = row / d.cls_cp, k = row - cls * d.cls_cp;
+      const int pi = cls >> 1, pj = cls & 1;
+      const int ta = t / d.ntw, tb = t - ta * d.ntw;
+      const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
+      const int r = pi + pad - 2 * dh, s2 = pj + pad - 2 * dw;
+      if (k < K && r >= 0 && r < R && s2 >= 0 && s2 < S) v = w[k * s_k + c * s_c + r * S + s2];
+    }
+    wp[e] = from_f<T>(v);
+  }
+}
+
 __global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp, float* __restrict__ dw, int splits,
                                    long slab_elems) {
   const int T_taps = d.nth * d.ntw;
@@ -794,7 +824,7 @@ int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int npix = d.Hg * d.Wg;
   const int mtiles = d.flat_m ? (int)(((long)d.N * npix + BM - 1) / BM) : ((npix + BM - 1) / BM) * d.N;
-  const int ntiles = (d.Cp_out + BN - 1) / BN;
+  const int ntiles = (d.n_extent + BN - 1) / BN;
   dim3 grid((unsigned)mtiles, (unsigned)ntiles);
   hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
   return p2phd::check_launch("gconv");
@@ -805,7 +835,8 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
                    float* stats, hipStream_t st) {
   // N tile: the 128-wide tile has the best MFMA density (64x64 per wave) and reads the gathered A operand once;
   // narrower tiles only for layers that would leave most of it empty
-  const int k = d.Cp_out;
+  if (d.n_extent == 0) d.n_extent = d.Cp_out;
+  const int k = d.n_extent;
   const int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
   const int npix = d.Hg * d.Wg;
   const int taps = d.nth * d.ntw;
@@ -855,7 +886,7 @@ int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, c
   {
     const size_t esz = dtype == P2PHD_BF16 ? 2 : 4;
     const size_t ib = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz;
-    const size_t wb = (size_t)round_up(d.Cp_out, 128) * d.KK * esz;   // packed rows are padded to 128
+    const size_t wb = (size_t)round_up(d.cls_cp > 0 ? 4 * d.cls_cp : d.Cp_out, 128) * d.KK * esz;   // packed rows are padded to 128
     P2PHD_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "gconv: tensor larger than 4 GiB");
     d.in_bytes = (unsigned)ib;
     d.w_bytes = (unsigned)wb;
@@ -946,6 +977,17 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
   const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
   hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, m, dwp, dw, splits, slab);
   return check_launch("unpack_grad");
+}
+
+int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int rows_pad, int K, int C, int R, int S, int pad,
+                       long s_k, long s_c, hipStream_t st) {
+  const long total = (long)rows_pad * d.KK;
+  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(pack_merged_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, d, w, (bf16_t*)wp, rows_pad, K, C, R, S, pad, s_k, s_c);
+  else
+    hipLaunchKernelGGL(pack_merged_kernel<float>, dim3(blocks), dim3(256), 0, st, d, w, (float*)wp, rows_pad, K, C, R, S, pad, s_k, s_c);
+  return check_launch("pack_weights(merged)");
 }
 
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {

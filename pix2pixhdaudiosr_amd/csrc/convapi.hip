@@ -108,6 +108,35 @@ void transposed_plans(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
     }
 }
 
+// Merged sub-pixel plan for stride 2 (the four residue classes of a transposed-form op in ONE launch): GEMM row =
+// input-resolution pixel (a, b), GEMM columns = (class, channel), taps (dh, dw) in {lo..hi}^2 shared by all classes with
+// zero weights where a class does not use a tap.  The gathered tensor is read once instead of four times and a
+// workgroup writes whole runs of adjacent output pixels instead of every other one.
+bool merged_plan(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Kout, int R, int S, int pad, Plan* out) {
+  // dh = (pi + pad - r) / 2 over all classes and kernel rows with (pi + pad - r) even
+  int lo = 1 << 30, hi = -(1 << 30);
+  for (int pi = 0; pi < 2; ++pi)
+    for (int r = 0; r < R; ++r)
+      if (((pi + pad - r) & 1) == 0) { const int dh = (pi + pad - r) / 2; lo = std::min(lo, dh); hi = std::max(hi, dh); }
+  int lo_w = 1 << 30, hi_w = -(1 << 30);
+  for (int pj = 0; pj < 2; ++pj)
+    for (int s = 0; s < S; ++s)
+      if (((pj + pad - s) & 1) == 0) { const int dw = (pj + pad - s) / 2; lo_w = std::min(lo_w, dw); hi_w = std::max(hi_w, dw); }
+  if (lo > hi || lo_w > hi_w) return false;
+  Plan p{};
+  GDesc& d = p.d;
+  d = base_desc(N);
+  d.Hin = Hin; d.Win = Win; d.Cp_in = cpitch(Cin);
+  d.Hg = (Hout + 1) / 2; d.Wg = (Wout + 1) / 2; d.pad_mode = 0;
+  d.Hout = Hout; d.Wout = Wout; d.Cp_out = cpitch(Kout); d.Kout = Kout;
+  d.cls_cp = d.Cp_out; d.n_extent = 4 * d.Cp_out;
+  d.nth = hi - lo + 1; d.ntw = hi_w - lo_w + 1; d.dh0 = lo; d.dw0 = lo_w;
+  d.KK = std::max(64, round_up(d.nth * d.ntw * d.Cp_in, 64));
+  p.rows_pad = round_up(4 * d.Cp_out, 128);
+  *out = p;
+  return true;
+}
+
 // ---- W-fold plans (stride 1, not transposed) ----
 // output fold, forward: Y[n,ho,w',(tw,k)] on the grid Ho x Wy, Wy = Wo + S - 1
 Plan kfold_fwd_plan(const p2phd_conv_desc* c, int Ho, int Wo) {
@@ -165,12 +194,18 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
     plans.push_back(direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode));
     *m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
   } else if (which == 0 && c->transposed) {
-    transposed_plans(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, plans);
+    Plan mp;
     *m = plain_map(c->K, c->C, RS, c->K * RS, c->S);                          // weight [C][K][R][S]
+    if (c->stride == 2 && merged_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->pad, &mp)) plans.push_back(mp);
+    else transposed_plans(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, plans);
   } else if (which == 1 && !c->transposed) {
     const int P = c->pad_mode == 1 ? c->pad : 0;                               // reflect: gradient on the padded grid
-    transposed_plans(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->stride, c->pad_mode == 1 ? 0 : c->pad, plans);
+    Plan mp;
     *m = plain_map(c->C, c->K, RS, c->C * RS, c->S);                          // weight [K][C][R][S]
+    if (c->stride == 2 && merged_plan(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->pad_mode == 1 ? 0 : c->pad, &mp))
+      plans.push_back(mp);
+    else
+      transposed_plans(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->stride, c->pad_mode == 1 ? 0 : c->pad, plans);
   } else {
     plans.push_back(direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0));
     *m = plain_map(c->C, c->K, c->K * RS, RS, c->S);                          // weight [C][K][R][S]
@@ -218,7 +253,12 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   make_plans(c, which, plans, &m);
   for (auto& p : plans) {
     char* dst = static_cast<char*>(packed) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
+    if (p.d.cls_cp > 0) {
+      // rows = m.rows output channels, inner = m.inner reduction channels, master strides from the plain map
+      const int pad_eff = (which == 1 && c->pad_mode == 1) ? 0 : c->pad;
+      if (int rc = launch_pack_merged(p.d, c->dtype, w, dst, p.rows_pad, m.rows, m.inner, c->R, c->S, pad_eff, m.s_row, m.s_inner,
+                                      (hipStream_t)stream)) return rc;
+    } else if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
   }
   return P2PHD_OK;
 }

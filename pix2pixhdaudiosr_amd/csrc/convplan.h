@@ -15,6 +15,9 @@ struct GDesc {
   int nth, ntw, dh0, dh_step, dw0, dw_step;   // tap (a,b): offset (dh0+a*dh_step, dw0+b*dw_step)
   int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
   int flat_m;                                 // M tiles run over all N*Hg*Wg pixels (set by the launcher)
+  int cls_cp;                                 // > 0: merged sub-pixel launch, GEMM column = class * cls_cp + channel,
+                                              //      class (pi,pj) = (col / cls_cp) writes output pixel (2*ho+pi, 2*wo+pj)
+  int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
 };
 
@@ -45,6 +48,8 @@ int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, cons
 size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad);
 int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
                  const void* gat, float* dwp, float* dw, hipStream_t st);
+int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int rows_pad, int K, int C, int R, int S, int pad,
+                       long s_k, long s_c, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);

@@ -25,22 +25,38 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
   return t;   // valid in thread 0
 }
 
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPP = 4; };
+template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
+
 // kind 0: (a - target)^2 ; kind 1: |a - b|.  a,b are [P][Cp] with C valid channels.  out += coeff * sum / (P*C)
+// 16-byte pieces, two in flight per thread; pad channels are masked
 template <typename T>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, float target,
                                                        long P, int C, int Cp, float coeff, float* __restrict__ out) {
+  constexpr int EPP = Elem<T>::EPP;
   __shared__ float red[4];
-  const long total = P * C;
+  const int cpr = Cp / EPP;
+  const long pieces = P * cpr;
   float acc = 0.f;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const long p = e / C;
-    const int c = (int)(e - p * C);
-    const float av = to_f(a[(size_t)p * Cp + c]);
-    if (kind == 0) { const float d = av - target; acc += d * d; }
-    else acc += fabsf(av - to_f(b[(size_t)p * Cp + c]));
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pieces; e += (long)gridDim.x * 256) {
+    const int c0 = (int)(e % cpr) * EPP;
+    const uint4 av = *reinterpret_cast<const uint4*>(a + e * EPP);
+    uint4 bv = make_uint4(0, 0, 0, 0);
+    if (kind == 1) bv = *reinterpret_cast<const uint4*>(b + e * EPP);
+    const T* aa = reinterpret_cast<const T*>(&av);
+    const T* bb = reinterpret_cast<const T*>(&bv);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      if (c0 + k < C) {
+        const float x = to_f(aa[k]);
+        if (kind == 0) { const float dlt = x - target; acc += dlt * dlt; }
+        else acc += fabsf(x - to_f(bb[k]));
+      }
+    }
   }
   const float t = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t * coeff / (float)total);
+  if (threadIdx.x == 0) atomicAdd(out, t * coeff / (float)(P * C));
 }
 
 // da[p][c] = (*gup) * coeff * f'(a) / (P*C), pad channels zero
@@ -48,17 +64,30 @@ template <typename T>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, float target,
                                                        long P, int C, int Cp, float coeff, const float* __restrict__ gup,
                                                        T* __restrict__ da) {
-  const long total = P * Cp;
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long pieces = P * cpr;
   const float s = (*gup) * coeff / (float)(P * C);
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int c = (int)(e % Cp);
-    float g = 0.f;
-    if (c < C) {
-      const float av = to_f(a[e]);
-      if (kind == 0) g = 2.f * (av - target) * s;
-      else { const float d = av - to_f(b[e]); g = d > 0.f ? s : (d < 0.f ? -s : 0.f); }
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < pieces; e += (long)gridDim.x * 256) {
+    const int c0 = (int)(e % cpr) * EPP;
+    const uint4 av = *reinterpret_cast<const uint4*>(a + e * EPP);
+    uint4 bv = make_uint4(0, 0, 0, 0);
+    if (kind == 1) bv = *reinterpret_cast<const uint4*>(b + e * EPP);
+    const T* aa = reinterpret_cast<const T*>(&av);
+    const T* bb = reinterpret_cast<const T*>(&bv);
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      float g = 0.f;
+      if (c0 + k < C) {
+        const float x = to_f(aa[k]);
+        if (kind == 0) g = 2.f * (x - target) * s;
+        else { const float dlt = x - to_f(bb[k]); g = dlt > 0.f ? s : (dlt < 0.f ? -s : 0.f); }
+      }
+      oo[k] = from_f<T>(g);
     }
-    da[e] = from_f<T>(g);
+    *reinterpret_cast<uint4*>(da + e * EPP) = ov;
   }
 }
 
@@ -105,9 +134,9 @@ extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b,
   const int Cp = (C + 7) & ~7;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * C, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out);
+    hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out);
   else if (dtype == P2PHD_F32)
-    hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(grid_for(P * C, 1024)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, out);
+    hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, out);
   else { p2phd::set_error("loss_fwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
   return p2phd::check_launch("loss_fwd");
 }
@@ -120,9 +149,9 @@ extern "C" int p2phd_loss_bwd(int kind, int dtype, const void* a, const void* b,
   const int Cp = (C + 7) & ~7;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(grid_for(P * Cp)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, grad_out, (bf16_t*)da);
+    hipLaunchKernelGGL(loss_bwd_kernel<bf16_t>, dim3(grid_for(P * Cp / 8)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, grad_out, (bf16_t*)da);
   else if (dtype == P2PHD_F32)
-    hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(grid_for(P * Cp)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, grad_out, (float*)da);
+    hipLaunchKernelGGL(loss_bwd_kernel<float>, dim3(grid_for(P * Cp / 8)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, grad_out, (float*)da);
   else { p2phd::set_error("loss_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
   return p2phd::check_launch("loss_bwd");
 }
