@@ -240,6 +240,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
       if (ks < 3) {
         read_frags(ks + 1, buf ^ 1);
         if constexpr (MR + NR == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        else if constexpr (MR + NR == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
         else if constexpr (MR + NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         else if constexpr (MR + NR == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
@@ -861,6 +862,16 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   if (force == 128) { big = false; huge = false; }
   if (force == 256) { big = fits3 || fits2; huge = false; }
   if (force == 512) { huge = fits_huge && k > 128; }
+  // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
+  // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
+  if (force == 192 && sizeof(T) == 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
+    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
+  if (huge && force == 0 && k % 192 == 0) {
+    const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
+    const double c256 = std::ceil(wg256 / 256.0) * 256.0 * 256.0, c192 = std::ceil(wg192 / 256.0) * 256.0 * 192.0 / 0.95;
+    if (c192 < c256 && 2 * 448 * kRowBytes + tabb <= kLds)
+      return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
+  }
   if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st);
   if (big && bn == 128) {
     if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);

@@ -96,7 +96,7 @@ def test_conv_block(case, dtype, tol):
         assert rel_err(grd[3].cpu().numpy(), gro[3].numpy()) < gt
 
 
-@pytest.mark.parametrize("bm", [128, 256, 512])
+@pytest.mark.parametrize("bm", [128, 256, 192, 512])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
 def test_tile_heights_agree_with_oracle(bm, dtype, tol):
     """Both M-tile heights of the gather conv (128 rows / 2-slot ring, 256 rows / 3-slot ring with counted vmcnt) on
@@ -104,6 +104,7 @@ def test_tile_heights_agree_with_oracle(bm, dtype, tol):
     from pix2pixhdaudiosr_amd import _ops, _lib
     cases = [(96, 136, 3, 1, 1, 1, (2, 24, 20)),      # reflect 3x3, K not a multiple of 64, 2 N tiles
              (64, 264, 3, 1, 1, 1, (2, 20, 18)),      # > 256 output channels: two 256-wide N tiles with a ragged tail
+             (72, 384, 3, 1, 1, 1, (2, 18, 16)),      # 384 = 2 x 192: the 256x192 tile
              (64, 64, 4, 2, 2, 0, (2, 34, 30)),       # D-style 4x4 s2, BN 64
              (72, 128, 3, 2, 1, 0, (1, 47, 33))]      # odd sizes
     _lib.check(_lib.lib().p2phd_set_option(b"gconv_bm", bm))
