@@ -77,6 +77,26 @@ int p2phd_imdct4_fwd(const float* spec, int64_t B, int64_t n_frames, int n_fft, 
                      float scale, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * MDCT2 / IMDCT2 and the DCT-II / DCT-III operators DCT_2N_native / IDCT_2N_native
+ * (models/mdct.py:352-454, dct/dct_native.py:7-68; native counterparts dct/src/dct_2N_cuda.cpp,
+ * dct_cuda_kernel.cu:267-406).  n_fft a power of two in [16, 1024]; tables as for MDCT4.
+ *   forward  out[b,t,k] = scale * c_k * (2/N) * sum_i w[i] xpad[b, t*hop+i] cos(pi (2i+1) k / 2N), c_0 = k0_scale
+ *   inverse  y_t[i]     = k0_scale * S[b,t,0] + 2 * sum_{k>=1} S[b,t,k] cos(pi (2i+1) k / 2N);
+ *            out[b,m]   = scale * sum_t w[q] y_t[q], q = m + crop_start - t*hop in [0,win)
+ * MDCT2.forward = forward(scale 1, k0 1); IMDCT2.forward = inverse(scale 1/2, k0 1); a plain DCT_2N_native on rows
+ * [R,N] = forward with B = R, T = N, hop = win = N, window of ones, one frame per row (IDCT likewise);
+ * autograd adjoints: forward^T = inverse(scale s/N, k0 2*k0), inverse^T = forward(scale s*N, k0 k0/2).
+ * ---------------------------------------------------------------------------------------- */
+size_t p2phd_dct_tables_floats(int n_fft);
+int p2phd_dct_tables_fill(int n_fft, float* host_out);
+int p2phd_mdct2_fwd(const float* x, int64_t B, int64_t T, int n_fft, int hop, int win, const float* window,
+                    const float* tables, int64_t start_pad, int64_t n_frames, float scale, float k0_scale,
+                    float* out, void* stream);
+int p2phd_imdct2_fwd(const float* spec, int64_t B, int64_t n_frames, int n_fft, int hop, int win, const float* window,
+                     const float* tables, int64_t crop_start, int64_t out_len, float scale, float k0_scale,
+                     float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Activation tensors of the conv stack are NHWC ("channels last": [N, H, W, Cp]) with the channel
  * pitch Cp = p2phd_channel_pitch(C) = C rounded up to 8; pad channels hold zeros.  dtype is
  * P2PHD_F32 (exact-f32 MFMA, parity runs) or P2PHD_BF16 (bf16 MFMA, fp32 accumulate).

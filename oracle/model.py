@@ -197,3 +197,21 @@ def full_step(hr, lr, noise, pG, pD, opt, window, stateG, stateD):
     pG = adam_step(dict(pG), gG, stateG, opt.lr, opt.beta1)
     pD = adam_step(dict(pD), gD, stateD, opt.lr, opt.beta1)
     return L, pG, pD
+
+
+def to_frames_mdct2(log_spectro, norm_param, opt):
+    """pix2pixHD_model.py:251-258 with IDCT_2N_native as the frame operator (oracle/mdct2.py)."""
+    from . import mdct2 as M2
+    s = denormalize(log_spectro, norm_param, opt)
+    s = (s[..., 0, :, :] - s[..., 1, :, :]) / (2 * opt.alpha - 1)
+    return torch.from_numpy(M2.idct_2n(s.permute(0, 2, 1).contiguous().double().numpy()))
+
+
+def match_loss(sr, norm_param, opt, window, lambda_mat=10.0):
+    """pix2pixHD_model.py:408-415."""
+    half = opt.win_length // 2
+    fr = to_frames_mdct2(sr, norm_param, opt)
+    w = torch.as_tensor(window, dtype=torch.float64)
+    a = fr[..., :-1, half:] * w[:half]
+    b = fr[..., 1:, :half] * w[half:]
+    return float(((a - b) ** 2).mean()) * lambda_mat

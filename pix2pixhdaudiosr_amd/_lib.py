@@ -26,6 +26,10 @@ SIGNATURES = {
     "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     "p2phd_mdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
     "p2phd_imdct4_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _vp, _vp]),
+    "p2phd_dct_tables_floats": (C.c_size_t, [_i32]),
+    "p2phd_dct_tables_fill": (_i32, [_i32, _vp]),
+    "p2phd_mdct2_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "p2phd_imdct2_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "p2phd_channel_pitch": (_i32, [_i32]),
     "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),

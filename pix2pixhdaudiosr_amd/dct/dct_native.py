@@ -1,0 +1,44 @@
+"""DCT_2N_native / IDCT_2N_native with the reference's scaling (dct/dct_native.py:7-68) on csrc/dct.hip:
+
+    DCT_2N_native(x)[k]  = (2/N) * sum_i x[i] cos(pi (2i+1) k / 2N)
+    IDCT_2N_native(X)[i] = X[0] + 2 * sum_{k>=1} X[k] cos(pi (2i+1) k / 2N)        (so idct(dct(a)) = 2a)
+
+over the last dimension (a power of two in [16, 1024]); differentiable; GPU only.
+"""
+import torch
+from torch import nn
+
+from ..models import mdct as _m
+
+
+def _rows(x):
+    N = x.size(-1)
+    if N < 16 or N > 1024 or (N & (N - 1)):
+        raise NotImplementedError("HIP DCT: last dimension must be a power of two in [16, 1024], got %d" % N)
+    if not x.is_cuda:
+        raise RuntimeError("HIP DCT runs on the GPU only")
+    return x.reshape(-1, N).to(torch.float32).contiguous(), N
+
+
+class DCT_2N_native(nn.Module):
+    def __init__(self, expk=None):
+        super(DCT_2N_native, self).__init__()
+        self.expk = expk          # kept for signature compatibility; the twiddles live in the kernel tables
+
+    def forward(self, x):
+        rows, N = _rows(x)
+        ones = torch.ones(N, dtype=torch.float32, device=x.device)
+        y = _m._MDCT2Fn.apply(rows, N, N, N, ones, _m._DctTables.get(N, x.device), 0, 1, 1.0, 1.0)
+        return y.reshape(x.shape)
+
+
+class IDCT_2N_native(nn.Module):
+    def __init__(self, expk=None):
+        super(IDCT_2N_native, self).__init__()
+        self.expk = expk
+
+    def forward(self, x):
+        rows, N = _rows(x)
+        ones = torch.ones(N, dtype=torch.float32, device=x.device)
+        y = _m._IMDCT2Fn.apply(rows.reshape(-1, 1, N), N, N, N, ones, _m._DctTables.get(N, x.device), 0, N, 1.0, 1.0)
+        return y.reshape(x.shape)

@@ -7,8 +7,9 @@ feat, infer)`` returning ``[filtered losses, sr or None]``; ``inference``; ``enc
 ``save`` / ``update_fixed_params`` / ``update_learning_rate``; checkpoint file names and state_dict keys.
 
 Deliberate differences:
-  * the transform is MDCT4/IMDCT4 (n_fft/2 bins -- the 512x256 geometry of BASELINE.json); the shipped
-    reference hard-codes MDCT2 (pix2pixHD_model.py:37-40) and invites the swap in README.md:133;
+  * the transform defaults to MDCT4/IMDCT4 (n_fft/2 bins -- the 512x256 geometry of BASELINE.json); the shipped
+    reference hard-codes MDCT2 (pix2pixHD_model.py:37-40) and invites the swap in README.md:133; ``opt.mdct_type =
+    'mdct2'`` selects the reference's own MDCT2/IMDCT2 (n_fft bins) and enables to_frames / --use_match_loss;
   * MDCT output is fp32 (the reference's complex128 twiddles make it fp64, which its own fp32 convs reject);
   * only the configuration the published runs use is on the path: explicit_encoding, mask_mode in
     {None, 'mode2'}, LSGAN, no VGG / hifigan / time-domain discriminator / feature encoder;
@@ -25,7 +26,7 @@ from ..optim import FlatAdam
 from ..util.util import kbdwin
 from . import networks
 from .base_model import BaseModel
-from .mdct import MDCT4, IMDCT4
+from .mdct import MDCT4, IMDCT4, MDCT2, IMDCT2
 
 
 def _opt(opt, name, default):
@@ -53,7 +54,7 @@ class Pix2PixHDModel(BaseModel):
             unsupported.append("explicit_encoding must be set (the published configuration)")
         if _opt(opt, 'mask_mode', None) not in (None, 'mode2'):
             unsupported.append("mask_mode must be None or 'mode2'")
-        for flag in ('use_hifigan_D', 'use_time_D', 'use_match_loss', 'instance_feat', 'label_feat'):
+        for flag in ('use_hifigan_D', 'use_time_D', 'instance_feat', 'label_feat'):
             if _opt(opt, flag, False):
                 unsupported.append("--%s is outside the HIP hot path" % flag)
         if not _opt(opt, 'no_vgg_loss', True):
@@ -66,6 +67,10 @@ class Pix2PixHDModel(BaseModel):
             unsupported.append("label_nc must be 0 (audio)")
         if _opt(opt, 'pool_size', 0) != 0:
             unsupported.append("pool_size must be 0 (the reference default; ImagePool is a no-op then)")
+        if _opt(opt, 'use_match_loss', False) and _opt(opt, 'mdct_type', 'mdct4') != 'mdct2':
+            unsupported.append("--use_match_loss compares DCT frames: it needs mdct_type='mdct2'")
+        if _opt(opt, 'mdct_type', 'mdct4') not in ('mdct4', 'mdct2'):
+            unsupported.append("mdct_type must be 'mdct4' or 'mdct2'")
         if unsupported:
             raise NotImplementedError("Pix2PixHDModel (HIP path): " + "; ".join(unsupported))
 
@@ -84,8 +89,17 @@ class Pix2PixHDModel(BaseModel):
         self.up_ratio = opt.hr_sampling_rate / opt.lr_sampling_rate
         self.window = kbdwin(opt.win_length).to(self.device)
         kw = dict(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=self.window, device=self.device)
-        self._mdct = MDCT4(**kw)
-        self._imdct = IMDCT4(**kw)
+        # mdct_type 'mdct4' (default: n_fft/2 bins, the BASELINE 512x256 geometry) or 'mdct2' (what the shipped
+        # reference hard-codes, pix2pixHD_model.py:37-40: n_fft bins through DCT_2N_native / IDCT_2N_native)
+        self.mdct_type = _opt(opt, 'mdct_type', 'mdct4')
+        if self.mdct_type == 'mdct2':
+            from ..dct.dct_native import DCT_2N_native, IDCT_2N_native
+            self._dct, self._idct = DCT_2N_native(), IDCT_2N_native()
+            self._mdct = MDCT2(dct_op=self._dct, **kw)
+            self._imdct = IMDCT2(idct_op=self._idct, **kw)
+        else:
+            self._mdct = MDCT4(**kw)
+            self._imdct = IMDCT4(**kw)
 
         ##### networks
         verbose = _opt(opt, 'verbose', False)
@@ -107,7 +121,7 @@ class Pix2PixHDModel(BaseModel):
 
         if self.isTrain:
             self.old_lr = opt.lr
-            self.loss_filter = self.init_loss_filter(not opt.no_ganFeat_loss, False, False, False)
+            self.loss_filter = self.init_loss_filter(not opt.no_ganFeat_loss, False, bool(_opt(opt, 'use_match_loss', False)), False)
             self.criterionGAN = networks.GANLoss(use_lsgan=True, tensor=self.Tensor)
             self.criterionFeat = networks.FeatLoss()
             self.loss_names = self.loss_filter('G_GAN', 'G_GAN_Feat', 'G_VGG', 'G_mat', 'G_GAN_t', 'D_real_t', 'D_fake_t', 'D_real', 'D_fake')
@@ -180,7 +194,13 @@ class Pix2PixHDModel(BaseModel):
         return np.sqrt(self.up_ratio - 1) * self._imdct(spec)
 
     def to_frames(self, log_spectro, norm_param):
-        raise NotImplementedError("to_frames (IDCT per frame, use_match_loss) is a next-row item (SURVEY 8f.1)")
+        """Un-windowed time-domain frames of an MDCT2 spectrogram (pix2pixHD_model.py:251-258): differentiable, the
+        IDCT runs on the HIP kernel; the small dB decode in front of it is plain tensor arithmetic."""
+        if self.mdct_type != 'mdct2':
+            raise NotImplementedError("to_frames needs mdct_type='mdct2' (frames are IDCT_2N_native rows)")
+        spectro = self.denormalize(log_spectro, norm_param)
+        spectro = (spectro[..., 0, :, :] - spectro[..., 1, :, :]) / (2 * self.opt.alpha - 1)
+        return self._idct(spectro.permute(0, 2, 1).contiguous())
 
     def encode_input(self, lr_audio, inst_map=None, hr_audio=None, feat_map=None, noise=None):
         with torch.no_grad():
@@ -236,10 +256,20 @@ class Pix2PixHDModel(BaseModel):
                     (a, c), (b, _) = pred_fake[i][j], pred_real[i][j]
                     loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, D_weights * feat_weights * self.opt.lambda_feat)
 
+        # TDAC frame-matching loss (pix2pixHD_model.py:408-415): the second half of frame t and the first half of frame
+        # t+1, each under its window half, must coincide
+        loss_G_match = 0
+        if _opt(self.opt, 'use_match_loss', False):
+            half = self.opt.win_length // 2
+            sr_frames = self.to_frames(sr_result, lr_norm_param)
+            a = sr_frames[..., :-1, half:] * self.window[:half]
+            b = sr_frames[..., 1:, :half] * self.window[half:]
+            loss_G_match = torch.nn.functional.mse_loss(a, b) * self.opt.lambda_mat
+
         # visuals are fetched lazily (no device->host copy in the step)
         self._visual = (lr_spectro, sr_result.detach(), hr_spectro, hr_pha)
 
-        return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, 0, 0, 0, 0, loss_D_real, loss_D_fake),
+        return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, loss_G_match, 0, 0, 0, loss_D_real, loss_D_fake),
                 None if not infer else sr_result]
 
     def inference(self, lr_audio, inst, noise=None):
@@ -256,7 +286,7 @@ class Pix2PixHDModel(BaseModel):
         losses, _ = self.forward(lr_audio, None, hr_audio, None, infer=False, noise=noise)
         ld = dict(zip(self.loss_names, losses))
         loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
-        loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0)
+        loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
         self.optimizer_G.zero_grad()
         self.optimizer_D.zero_grad()
         g_params = [p for p in self.optimizer_G._params]

@@ -109,6 +109,55 @@ def gen_mdct(out):
     print("mdct4.npz", len(d), "arrays")
 
 
+def gen_mdct2(out):
+    """MDCT2 / IMDCT2 with the reference's DCT_2N_native / IDCT_2N_native (what the shipped model uses)."""
+    from models.mdct import MDCT2, IMDCT2
+    from dct.dct_native import DCT_2N_native, IDCT_2N_native
+    from util.util import kbdwin
+    d = {}
+    a = torch.arange(1, 17, dtype=torch.float32)
+    d["kat_in"] = _np(a)
+    d["kat_dct"] = _np(DCT_2N_native()(a))
+    d["kat_idct_dct"] = _np(IDCT_2N_native()(DCT_2N_native()(a)))
+    g = torch.Generator().manual_seed(99)
+    r = torch.randn(3, 5, 64, generator=g).requires_grad_(True)
+    y = DCT_2N_native()(r)
+    c = torch.randn(y.shape, generator=g)
+    (gr,) = torch.autograd.grad((y * c).sum(), r)
+    d["dct_x"] = _np(r); d["dct_y"] = _np(y); d["dct_cot"] = _np(c); d["dct_gx"] = _np(gr)
+    r2 = torch.randn(4, 128, generator=g).requires_grad_(True)
+    y2 = IDCT_2N_native()(r2)
+    c2 = torch.randn(y2.shape, generator=g)
+    (gr2,) = torch.autograd.grad((y2 * c2).sum(), r2)
+    d["idct_x"] = _np(r2); d["idct_y"] = _np(y2); d["idct_cot"] = _np(c2); d["idct_gx"] = _np(gr2)
+    cases = [("n16_b3", 16, 8, 16, (3, 72), True), ("n64_b2_odd", 64, 32, 64, (2, 470), True),
+             ("n64_hop16", 64, 16, 64, (2, 480), True), ("n64_win48", 64, 24, 48, (2, 480), True),
+             ("n64_nocenter", 64, 32, 64, (2, 480), False), ("n512_b2", 512, 256, 512, (2, 7 * 256), True),
+             ("n1024_b1", 1024, 512, 1024, (1, 5 * 512), True)]
+    meta = []
+    for name, n_fft, hop, win, shape, center in cases:
+        x = (torch.randn(*shape, generator=g) * 0.1).requires_grad_(True)
+        w = kbdwin(win)
+        d[f"{name}_w"] = _np(w)
+        mdct = MDCT2(n_fft=n_fft, hop_length=hop, win_length=win, window=w, center=center, device="cpu", dct_op=DCT_2N_native())
+        S = mdct(x)
+        cot = torch.randn(S.shape, generator=g)
+        (gx,) = torch.autograd.grad((S * cot).sum(), x)
+        imdct = IMDCT2(n_fft=n_fft, hop_length=hop, win_length=win, window=w, center=center, device="cpu", idct_op=IDCT_2N_native())
+        S2 = S.detach().clone().requires_grad_(True)
+        y = imdct(S2)
+        ycot = torch.randn(y.shape, generator=g)
+        (gS,) = torch.autograd.grad((y * ycot).sum(), S2)
+        imdct_ol = IMDCT2(n_fft=n_fft, hop_length=hop, win_length=win, window=w, center=center, device="cpu",
+                          out_length=shape[-1], idct_op=IDCT_2N_native())
+        for k, v in (("x", x), ("S", S), ("cot", cot), ("gx", gx), ("y", y), ("ycot", ycot), ("gS", gS), ("y_outlen", imdct_ol(S.detach()))):
+            d[f"{name}_{k}"] = _np(v)
+        meta.append(f"{name},{n_fft},{hop},{win},{int(center)}," + "x".join(map(str, shape)))
+    d["cases"] = np.array(meta)
+    np.savez_compressed(os.path.join(out, "mdct2.npz"), **d)
+    print("mdct2.npz", len(d), "arrays; KAT", d["kat_dct"][:4])
+
+
 def _sd(net):
     return OrderedDict((k, _np(v)) for k, v in net.state_dict().items())
 
@@ -292,7 +341,9 @@ def main():
     _stub_modules()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
-    todo = a.only.split(",") if a.only else ["mdct", "networks", "model"]
+    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model"]
+    if "mdct2" in todo:
+        gen_mdct2(a.out)
     if "mdct" in todo:
         gen_mdct(a.out)
     if "networks" in todo:
