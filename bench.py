@@ -112,10 +112,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (never set by the driver): run several ranks on one GPU over gloo to exercise the DP code path
+    backend = os.environ.get("P2PHD_DIST_BACKEND", "nccl")
+    if "P2PHD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["P2PHD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from pix2pixhdaudiosr_amd.models.models import create_model
     from pix2pixhdaudiosr_amd import parallel_state
 
