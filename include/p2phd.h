@@ -200,6 +200,28 @@ int p2phd_spectro_encode(const float* spec, int64_t B, int64_t F, int64_t M, flo
 int p2phd_spectro_decode(const float* log_spectro, const float* norm_min_max, int64_t B, int64_t F, int64_t M,
                          float alpha, float min_value, float* spec, void* stream);
 
+/* util.imdct's decode (util/util.py:104-126; caller generate_audio.py:40-42): log_spectro [B,channels,M,F] (magnitudes are
+ * taken), pha [B,M,F] (+-1), (min,max) -> signed amplitudes spec [B,F,M] * scale.  channels = 2 (explicit encoding):
+ * amplitude = ch0 + ch1, sign = pha on rows < keep_rows and sign(ch0 - ch1) on the rest; channels = 1: sign = pha on every
+ * row (the caller splices its random signs into pha, :122-123).  keep_rows = int(M * (1 / up_ratio)), or M. */
+int p2phd_spectro_decode_signed(const float* log_spectro, const float* pha, const float* norm_min_max, int64_t B, int64_t F,
+                                int64_t M, int channels, int keep_rows, float min_value, float scale, float* spec, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics (csrc/metrics.hip): compute_matrics (util/util.py:133-184).
+ * hr, lr, sr [B,T] f32.  sr_matched [B,T] receives sr moment-matched to hr (:139-140); result4 (device) receives
+ * (mse, snr_sr, snr_lr, lsd).  The LSD spectrogram is |STFT|^2 with n_fft2 = 2*opt.n_fft (power of two <= 4096),
+ * hop2 = 2*opt.hop_length, window2 = kbdwin(2*opt.win_length) of win2 samples, reflect-centred when center != 0
+ * (torchaudio.functional.spectrogram(pad=0, power=2, normalized=False) = torch.stft, :178-179).
+ * tables: p2phd_stft_tables_floats(n_fft2) floats filled on the host; workspace: p2phd_metrics_workspace_bytes bytes.
+ * ---------------------------------------------------------------------------------------- */
+size_t p2phd_stft_tables_floats(int n_fft2);
+int p2phd_stft_tables_fill(int n_fft2, float* host_out);
+size_t p2phd_metrics_workspace_bytes(int64_t B, int64_t T, int n_fft2, int hop2, int win2, int center);
+int p2phd_audio_metrics(const float* hr, const float* lr, const float* sr, int64_t B, int64_t T, int n_fft2, int hop2, int win2,
+                        const float* window2, const float* tables, int center, float* sr_matched, float* result4,
+                        void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libp2phd_hip.so")
 
 F32, BF16 = 0, 1
-_i64, _i32, _f32, _vp = C.c_int64, C.c_int, C.c_float, C.c_void_p
+_i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
 
 # name -> (restype, argtypes); must list every symbol of include/p2phd.h (tests check this)
 SIGNATURES = {
@@ -53,6 +53,11 @@ SIGNATURES = {
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_decode": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _vp]),
+    "p2phd_spectro_decode_signed": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
+    "p2phd_stft_tables_floats": (_sz, [_i32]),
+    "p2phd_stft_tables_fill": (_i32, [_i32, _vp]),
+    "p2phd_metrics_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "p2phd_audio_metrics": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 
 

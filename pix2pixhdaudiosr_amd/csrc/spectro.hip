@@ -134,6 +134,39 @@ __global__ __launch_bounds__(256) void decode_kernel(const float* __restrict__ x
   }
 }
 
+// util.imdct's decode (util/util.py:104-126): amplitude = sum of the channels, sign = pha below `keep` rows and
+// sign(ch0 - ch1) above (explicit encoding); single channel: sign = pha everywhere (the caller draws the random signs).
+__global__ __launch_bounds__(256) void decode_signed_kernel(const float* __restrict__ x, const float* __restrict__ pha,
+                                                            const float* __restrict__ norm2, float* __restrict__ spec, int F, int M,
+                                                            int channels, int keep, float min_value, float scale) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z, m0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const float mn = norm2[0], range = norm2[1] - norm2[0];
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty + 8 * i, f = f0 + tx;
+    float v = 0.f;
+    if (m < M && f < F) {
+      const size_t o = ((size_t)b * channels * M + m) * F + f;
+      const float a0 = 10.f * exp10f((fabsf(x[o]) * range + mn) * 0.05f) - min_value;
+      float sgn = pha[((size_t)b * M + m) * F + f];
+      float amp = a0;
+      if (channels == 2) {
+        const float a1 = 10.f * exp10f((fabsf(x[o + (size_t)M * F]) * range + mn) * 0.05f) - min_value;
+        amp = a0 + a1;
+        if (m >= keep) sgn = a0 > a1 ? 1.f : (a0 < a1 ? -1.f : 0.f);
+      }
+      v = amp * sgn * scale;
+    }
+    tile[ty + 8 * i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = 0; i < 4; ++i) {
+    const int f = f0 + ty + 8 * i, m = m0 + tx;
+    if (f < F && m < M) spec[((size_t)b * F + f) * M + m] = tile[tx][ty + 8 * i];
+  }
+}
+
 }  // namespace
 
 extern "C" int64_t p2phd_spectro_partials_floats(int64_t B, int64_t F, int64_t M) {
@@ -176,4 +209,19 @@ extern "C" int p2phd_spectro_decode(const float* log_spectro, const float* norm_
   dim3 grid((unsigned)((M + 31) / 32), (unsigned)((F + 31) / 32), (unsigned)B);
   hipLaunchKernelGGL(decode_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, log_spectro, norm_min_max, spec, (int)F, (int)M, alpha, min_value);
   return p2phd::check_launch("spectro_decode");
+}
+
+extern "C" int p2phd_spectro_decode_signed(const float* log_spectro, const float* pha, const float* norm_min_max, int64_t B,
+                                           int64_t F, int64_t M, int channels, int keep_rows, float min_value, float scale,
+                                           float* spec, void* stream) {
+  P2PHD_REQUIRE(B >= 0 && F >= 1 && M >= 1, "spectro_decode_signed: bad geometry");
+  P2PHD_REQUIRE(channels == 1 || channels == 2, "spectro_decode_signed: channels must be 1 or 2, got %d", channels);
+  P2PHD_REQUIRE(keep_rows >= 0 && keep_rows <= M, "spectro_decode_signed: keep_rows %d outside [0, %lld]", keep_rows, (long long)M);
+  if (B == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(log_spectro && pha && norm_min_max && spec, "spectro_decode_signed: null pointer");
+  P2PHD_REQUIRE(B < 65536 && (F + 31) / 32 < 65536, "spectro_decode_signed: grid too large");
+  dim3 grid((unsigned)((M + 31) / 32), (unsigned)((F + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(decode_signed_kernel, grid, dim3(32, 8), 0, (hipStream_t)stream, log_spectro, pha, norm_min_max, spec, (int)F,
+                     (int)M, channels, keep_rows, min_value, scale);
+  return p2phd::check_launch("spectro_decode_signed");
 }

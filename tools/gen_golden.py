@@ -4,8 +4,8 @@
 Runs only in the build container (needs /root/reference); the reference never travels to
 the GPU box, the small .npz fixtures do.  Absent third-party imports the reference pulls in
 at module import time are stubbed with empty modules: torchvision (VGG only),
-turtle (a stray import), pysepm, torchaudio (only the two dB one-liners are provided, pinned
-by the reference's own KAT from test/metrics_test.ipynb cell 11).
+turtle (a stray import), pysepm, torchaudio (only the two dB one-liners, pinned by the reference's
+own KAT from test/metrics_test.ipynb cell 11, and `spectrogram` = |torch.stft|^power are provided).
 
 Usage:  python tools/gen_golden.py [--out tests/golden]
 """
@@ -36,8 +36,17 @@ def _stub_modules():
 
     def DB_to_amplitude(x, ref, power):
         return ref * torch.pow(torch.pow(10.0, 0.1 * x), power)
+    def spectrogram(waveform, pad, window, n_fft, hop_length, win_length, power, normalized, center=True,
+                    pad_mode="reflect", onesided=True):
+        # torchaudio.functional.spectrogram by its documented definition (pad = 0, normalized = False on this path)
+        assert pad == 0 and not normalized
+        shape = waveform.shape
+        S = torch.stft(waveform.reshape(-1, shape[-1]), n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=window,
+                       center=center, pad_mode=pad_mode, normalized=False, onesided=onesided, return_complex=True)
+        return S.reshape(shape[:-1] + S.shape[-2:]).abs().pow(power)
     taf.amplitude_to_DB = amplitude_to_DB
     taf.DB_to_amplitude = DB_to_amplitude
+    taf.spectrogram = spectrogram
 
 
 def _np(t):
@@ -332,6 +341,61 @@ def gen_model(out):
     print("model_step.npz", len(d), "arrays; losses", dict(zip(names, d["loss_values"])))
 
 
+def gen_evaltail(out):
+    """util.imdct + compute_matrics (util/util.py:104-184) as generate_audio.py:40-49 calls them."""
+    import util.util as U
+    from models.mdct import IMDCT4
+    d = {}
+    g = torch.Generator().manual_seed(4321)
+    torch.Tensor.cuda = lambda self, *a, **k: self          # compute_matrics hard-codes kbdwin(...).cuda() (util.py:178)
+    # --- imdct: explicit and plain encodings, up_ratio 1 / 3 / 6 (6 -> int(H/6) is not a divisor of H)
+    n_fft, hop, H, W = 64, 32, 32, 9
+    for tag, B, explicit, up in (("ex_b2_u6", 2, True, 6.0), ("ex_b1_u3", 1, True, 3.0), ("ex_b2_u1", 2, True, 1.0),
+                                 ("pl_b2_u1", 2, False, 1.0), ("pl_b2_u6", 2, False, 6.0)):
+        C = 2 if explicit else 1
+        spectro = torch.rand(B, C, H, W, generator=g)
+        if explicit:
+            spectro[..., 3, 2] = spectro[..., :1, 3, 2]        # equal channels -> sign 0
+        pha = torch.sign(torch.randn(B, H, W, generator=g))
+        norm = {"min": torch.tensor(-140.0), "max": torch.tensor(-35.5)}
+        _imdct = IMDCT4(n_fft=n_fft, hop_length=hop, win_length=n_fft, window=U.kbdwin, out_length=(W - 1) * hop, device="cpu")
+        if not explicit and up > 1:
+            draws = []
+            real_randint = torch.randint
+
+            def fake_randint(low=0, high=2, size=None, device=None, **kw):
+                r = real_randint(low=low, high=high, size=tuple(size), generator=g)
+                draws.append(2 * r - 1)
+                return r
+            torch.randint = fake_randint
+            audio = U.imdct(spectro if explicit else spectro, pha.unsqueeze(1), norm, _imdct, up_ratio=up, explicit_encoding=explicit)
+            torch.randint = real_randint
+            d[f"imdct_{tag}_pseudo"] = _np(draws[0].to(torch.float32))
+        else:
+            audio = U.imdct(spectro, pha if explicit else pha.unsqueeze(1), norm, _imdct, up_ratio=up, explicit_encoding=explicit)
+        d[f"imdct_{tag}_spectro"] = _np(spectro)
+        d[f"imdct_{tag}_pha"] = _np(pha)
+        d[f"imdct_{tag}_audio"] = _np(audio)
+        d[f"imdct_{tag}_meta"] = np.array([n_fft, hop, H, W, int(explicit), up, -140.0, -35.5])
+    # --- compute_matrics
+    class O:
+        pass
+    for tag, B, T, N in (("n64_b3", 3, 1000, 64), ("n64_1d", 0, 777, 64), ("n1024_b2", 2, 9000, 1024), ("n64_nc", 2, 1000, 64)):
+        o = O(); o.n_fft = N; o.hop_length = N // 2; o.win_length = N; o.center = tag != "n64_nc"; o.hr_sampling_rate = 48000
+        shape = (T,) if B == 0 else (B, T)
+        hr = 0.1 * torch.randn(*shape, generator=g)
+        lr = hr + 0.03 * torch.randn(*shape, generator=g)
+        sr = 0.7 * hr + 0.02 * torch.randn(*shape, generator=g) + 0.01
+        mse, snr_sr, snr_lr, _, _, _, lsd = U.compute_matrics(hr, lr, sr, o)
+        d[f"met_{tag}_hr"] = _np(hr); d[f"met_{tag}_lr"] = _np(lr); d[f"met_{tag}_sr"] = _np(sr)
+        d[f"met_{tag}_out"] = np.array([mse, snr_sr, snr_lr, lsd])
+        d[f"met_{tag}_meta"] = np.array([N, N // 2, N, int(o.center)])
+        d[f"met_{tag}_win2"] = _np(U.kbdwin(2 * N))
+    d["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(out, "evaltail.npz"), **d)
+    print("evaltail.npz", len(d), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -341,7 +405,7 @@ def main():
     _stub_modules()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
-    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model"]
+    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model", "evaltail"]
     if "mdct2" in todo:
         gen_mdct2(a.out)
     if "mdct" in todo:
@@ -350,6 +414,8 @@ def main():
         gen_networks(a.out)
     if "model" in todo:
         gen_model(a.out)
+    if "evaltail" in todo:
+        gen_evaltail(a.out)
 
 
 if __name__ == "__main__":
