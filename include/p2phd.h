@@ -222,6 +222,21 @@ int p2phd_audio_metrics(const float* hr, const float* lr, const float* sr, int64
                         const float* window2, const float* tables, int center, float* sr_matched, float* result4,
                         void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Input feeder resampler (csrc/resample.hip): the HR -> LR -> HR conversions of data/audio_dataset.py:55-57,109-113
+ * (torchaudio.functional.resample there; its source is not in the reference, so the definition -- Hann-windowed sinc,
+ * lowpass_filter_width 6, rolloff 0.99 -- is this build's own, stated in oracle/feeder.py).
+ * x [B,T] f32 -> out [B,T_out], T_out = p2phd_resample_out_len(T, orig, new) = ceil(new*T/orig).
+ * kernel: p2phd_resample_kernel_floats floats, filled on the host by p2phd_resample_kernel_fill, then copied to the device.
+ * ---------------------------------------------------------------------------------------- */
+int p2phd_resample_geometry(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff, int* o, int* n, int* width,
+                            int* klen);
+size_t p2phd_resample_kernel_floats(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff);
+int p2phd_resample_kernel_fill(int orig_freq, int new_freq, int lowpass_filter_width, double rolloff, float* host_out);
+int64_t p2phd_resample_out_len(int64_t T, int orig_freq, int new_freq);
+int p2phd_resample_fwd(const float* x, int64_t B, int64_t T, int orig_freq, int new_freq, int lowpass_filter_width,
+                       double rolloff, const float* kernel, float* out, int64_t T_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,11 @@ SIGNATURES = {
     "p2phd_stft_tables_floats": (_sz, [_i32]),
     "p2phd_stft_tables_fill": (_i32, [_i32, _vp]),
     "p2phd_metrics_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
+    "p2phd_resample_geometry": (_i32, [_i32, _i32, _i32, C.c_double, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
+    "p2phd_resample_kernel_floats": (_sz, [_i32, _i32, _i32, C.c_double]),
+    "p2phd_resample_kernel_fill": (_i32, [_i32, _i32, _i32, C.c_double, _vp]),
+    "p2phd_resample_out_len": (_i64, [_i64, _i32, _i32]),
+    "p2phd_resample_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, C.c_double, _vp, _vp, _i64, _vp]),
     "p2phd_audio_metrics": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
 }
 

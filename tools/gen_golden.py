@@ -26,7 +26,7 @@ def _stub_modules():
         m = types.ModuleType(name)
         sys.modules[name] = m
         return m
-    tv = mod("torchvision"); tv.models = mod("torchvision.models")
+    tv = mod("torchvision"); tv.models = mod("torchvision.models"); tv.transforms = mod("torchvision.transforms")
     mod("turtle").forward = None
     mod("pysepm")
     ta = mod("torchaudio"); taf = mod("torchaudio.functional"); ta.functional = taf
@@ -396,6 +396,34 @@ def gen_evaltail(out):
     print("evaltail.npz", len(d), "arrays")
 
 
+def gen_feeder(out):
+    """seg_pad_audio of both datasets (data/audio_dataset.py:81-88,124-135) called on a bare object, plus an excerpt of
+    the reference's own test clip (test/test.wav, PCM16 mono 48 kHz) as the feeder's real-audio fixture."""
+    import wave
+    from data.audio_dataset import AudioDataset, AudioTestDataset
+    d = {}
+    g = torch.Generator().manual_seed(99)
+
+    class Bare:
+        pass
+    for tag, shape, seg in (("train_long", (1, 50), 32), ("train_exact", (1, 32), 32), ("train_short", (1, 20), 32),
+                            ("train_stereo_long", (2, 40), 32)):
+        o = Bare(); o.segment_length = seg
+        w = torch.randn(*shape, generator=g)
+        d[f"seg_{tag}_in"] = _np(w); d[f"seg_{tag}_out"] = _np(AudioDataset.seg_pad_audio(o, w)); d[f"seg_{tag}_len"] = np.array(seg)
+    for tag, shape, seg in (("test_multi", (1, 100), 32), ("test_exact", (1, 64), 32), ("test_short", (1, 20), 32), ("test_1d", (70,), 32)):
+        o = Bare(); o.segment_length = seg
+        w = torch.randn(*shape, generator=g)
+        d[f"seg_{tag}_in"] = _np(w); d[f"seg_{tag}_out"] = _np(AudioTestDataset.seg_pad_audio(o, w)); d[f"seg_{tag}_len"] = np.array(seg)
+    with wave.open(os.path.join(REF, "test", "test.wav")) as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 48000)
+        w.setpos(96000)
+        d["test_wav_excerpt_i16"] = np.frombuffer(w.readframes(24000), dtype="<i2").copy()
+    d["test_wav_rate"] = np.array(48000)
+    np.savez_compressed(os.path.join(out, "feeder.npz"), **d)
+    print("feeder.npz", len(d), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -405,7 +433,7 @@ def main():
     _stub_modules()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
-    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model", "evaltail"]
+    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model", "evaltail", "feeder"]
     if "mdct2" in todo:
         gen_mdct2(a.out)
     if "mdct" in todo:
@@ -416,6 +444,8 @@ def main():
         gen_model(a.out)
     if "evaltail" in todo:
         gen_evaltail(a.out)
+    if "feeder" in todo:
+        gen_feeder(a.out)
 
 
 if __name__ == "__main__":
