@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2phd_hip.so")
+# P2PHD_LIB: load another build of the same ABI (kernel A/B and ablation experiments, tools/ablate_gconv.py)
+LIB_PATH = os.environ.get("P2PHD_LIB") or os.path.join(_HERE, "libp2phd_hip.so")
 
 F32, BF16 = 0, 1
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t

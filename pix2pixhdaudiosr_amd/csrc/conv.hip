@@ -71,6 +71,11 @@ constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
 // ------------------------------------------------------------------------------------------------------
 // gather convolution
 // ------------------------------------------------------------------------------------------------------
+#ifdef P2PHD_PROBE
+// experiment builds only (tools/ablate_gconv.sh): per-wave cycle totals of the main loop's wait / barrier / compute parts
+__device__ unsigned long long g_probe[4];
+#endif
+
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
 __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
                                                     const float* __restrict__ bias, const T* __restrict__ addend,
@@ -217,85 +222,145 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     }
   }
 
-  // One K slab (4 MFMA k-steps) from ring slot `slot`; when `pf` the NLOADS pieces of tile `pf_tile` are issued into
-  // ring slot `pf_slot` spread over the four k-steps, so each LDS-DMA issue hides behind an MFMA cluster.
-  auto compute = [&](int slot, bool pf, int pf_slot, int pf_tile) {
-    const unsigned so = (unsigned)(slot * STAGE);
-    uint4 af[2][MR], bfr[2][NR];
-    auto read_frags = [&](int ks, int buf) {
+  // ---- main loop -------------------------------------------------------------------------------------------
+  // NSTAGE-slot LDS ring; tile t lives in slot t % NSTAGE.  ONE workgroup barrier per K slab, placed in front of the
+  // slab's LAST MFMA cluster (k-step 3), after the wave has (a) every fragment of the slab in registers
+  // (lgkmcnt(0): its LDS reads of the slot are complete) and (b) its own LDS-DMA pieces of the NEXT tile landed
+  // (counted vmcnt).  Past that barrier
+  //   * the next tile is readable: its first fragments are fetched while the last cluster of this slab runs, so the
+  //     matrix pipe never waits for a barrier + LDS round trip at a slab boundary;
+  //   * this slab's slot is free: tile s + NSTAGE is issued into it at once (half now, half one k-step later), giving
+  //     the DMA more than a full slab of MFMA work to land, even on the 2-slot ring of the 256-wide tiles.
+  // The later tiles stay in flight ACROSS the barrier (raw s_barrier; __syncthreads() would drain them).
+  uint4 af[2][MR], bfr[2][NR];
+  auto read_frags = [&](unsigned so, int ks, int buf) {
+#ifdef P2PHD_ABL_NOLDSREAD
 #pragma unroll
-      for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"(fa[i][ks] + so));
+    for (int i = 0; i < MR; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(af[buf][i].x) : "v"(fa[i][ks] + so));
 #pragma unroll
-      for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"(fb[j][ks] + so));
-    };
-    read_frags(0, 0);
-    if (pf) prepare();
+    for (int j = 0; j < NR; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bfr[buf][j].x) : "v"(fb[j][ks] + so));
+#else
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int buf = ks & 1;
-      if (pf) {
+    for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"(fa[i][ks] + so));
 #pragma unroll
-        for (int j = ks; j < NLOADS; j += 4) issue_piece(pf_slot, pf_tile, j);
-      }
-      if (ks < 3) {
-        read_frags(ks + 1, buf ^ 1);
-        if constexpr (MR + NR == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        else if constexpr (MR + NR == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-        else if constexpr (MR + NR == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        else if constexpr (MR + NR == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"(fb[j][ks] + so));
+#endif
+  };
+  // One MFMA cluster (MR x NR tiles, one k-step); `h0` / `h1` are issued in the shadow of its first / second MFMA
+  // (fragment reads, LDS-DMA issue), so the matrix pipe already has work when the wave turns to them.
+  auto mfma_one = [&](int buf, int i, int j) {
+    if constexpr (sizeof(T) == 2) {
+#ifdef P2PHD_ABL_NOMFMA
+      asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
+#else
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
+                                                          *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);
+#endif
+    } else {
+      // exact f32 MFMA; any k permutation is fine as long as A and B share it
+      const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[buf][i]);
+      const f32x4 b4 = *reinterpret_cast<f32x4*>(&bfr[buf][j]);
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-          if constexpr (sizeof(T) == 2) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
-                                                                *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);
-          } else {
-            // exact f32 MFMA; any k permutation is fine as long as A and B share it
-            const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[buf][i]);
-            const f32x4 b4 = *reinterpret_cast<f32x4*>(&bfr[buf][j]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
-          }
-        }
-      __builtin_amdgcn_sched_barrier(0);
+      for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
     }
   };
-
-  // NSTAGE-slot LDS ring, prefetch distance D = NSTAGE - 1.  The loads of tiles s+1 .. s+D-1 stay in flight ACROSS
-  // the barrier of tile s (counted vmcnt + raw s_barrier; __syncthreads() would drain them).  Tile s+D is issued
-  // into the slot tile s-1 was read from, which every wave has left once it is past this barrier.
-  const int nsteps = KK / BK;
-  constexpr int D = NSTAGE - 1;
+  // the MFMAs of a cluster after its first `skip`
+  auto mfma_rest = [&](int buf, int skip) {
 #pragma unroll
-  for (int t = 0; t < D; ++t) {
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+        if (i * NR + j >= skip) mfma_one(buf, i, j);
+  };
+
+  const int nsteps = KK / BK;
+#pragma unroll
+  for (int t = 0; t < NSTAGE; ++t) {
     if (t < nsteps) {
       prepare();
 #pragma unroll
       for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
     }
   }
-  int cur = 0, nxt = D;
+  if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  read_frags(0u, 0, 0);
+
+  int cur = 0;
+  bool pend = false;                              // second half of a tile's pieces still to be issued (at k-step 0)
+  int pend_slot = 0, pend_tile = 0;
+#ifdef P2PHD_PROBE
+  unsigned long long pr_wait = 0, pr_bar = 0, pr_comp = 0;
+#endif
   for (int s = 0; s < nsteps; ++s) {
-    if (D >= 2 && s + 1 < nsteps) {
-      if constexpr (NLOADS == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned so = (unsigned)(cur * STAGE);
+    const int nslot = cur == NSTAGE - 1 ? 0 : cur + 1;
+#ifdef P2PHD_PROBE
+    const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
+    // Each k-step: its fragments were fetched behind the previous cluster and have had that cluster's time to land.
+    // The first MFMA goes out at once; the next fragment reads and the LDS-DMA issue follow in its shadow (written out
+    // inline: a closure that captures the unrolled `ks` turns the fragment-address arrays into scratch).
+    const bool has_next = s + 1 < nsteps;
+    const bool issue_new = s + NSTAGE < nsteps;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int buf = ks & 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (ks == 3 && has_next) {
+        // slab boundary: every LDS read of this slot is complete; own pieces of the next tile must have landed
+#ifdef P2PHD_PROBE
+        const unsigned long long pt1 = __builtin_readcyclecounter();
+#endif
+        if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef P2PHD_PROBE
+        const unsigned long long pt2 = __builtin_readcyclecounter();
+        pr_wait += pt2 - pt1;
+#endif
+        __builtin_amdgcn_s_barrier();
+#ifdef P2PHD_PROBE
+        pr_bar += __builtin_readcyclecounter() - pt2;
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_one(buf, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ks < 3) read_frags(so, ks + 1, buf ^ 1);
+      else if (has_next) read_frags((unsigned)(nslot * STAGE), 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (MR * NR > 1) mfma_one(buf, 1 / NR, 1 % NR);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef P2PHD_ABL_NODMA
+      if (ks == 0 && pend) {
+#pragma unroll
+        for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, pend_tile, j);
+        pend = false;
+      }
+      if (ks == 3 && issue_new) {
+        prepare();
+#pragma unroll
+        for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, s + NSTAGE, j);
+        pend = true; pend_slot = cur; pend_tile = s + NSTAGE;
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_rest(buf, MR * NR > 1 ? 2 : 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    compute(cur, s + D < nsteps, nxt, s + D);
-    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
-    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
+#ifdef P2PHD_PROBE
+    pr_comp += __builtin_readcyclecounter() - pt0;
+#endif
+    cur = nslot;
   }
+#ifdef P2PHD_PROBE
+  if (lane == 0) {
+    atomicAdd(&g_probe[0], pr_wait); atomicAdd(&g_probe[1], pr_bar); atomicAdd(&g_probe[2], pr_comp);
+    atomicAdd(&g_probe[3], (unsigned long long)nsteps);
+  }
+#endif
   __syncthreads();
 
   // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
@@ -1042,3 +1107,14 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hi
 }
 
 }  // namespace p2phd
+
+#ifdef P2PHD_PROBE
+extern "C" int p2phd_debug_probe(unsigned long long* out4, int reset) {
+  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
