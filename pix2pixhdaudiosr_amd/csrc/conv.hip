@@ -28,6 +28,7 @@
 #include "common.h"
 #include "convplan.h"
 #include <cmath>
+#include <type_traits>
 
 namespace {
 
@@ -73,7 +74,8 @@ constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
 // ------------------------------------------------------------------------------------------------------
 #ifdef P2PHD_PROBE
 // experiment builds only (tools/ablate_gconv.sh): per-wave cycle totals of the main loop's wait / barrier / compute parts
-__device__ unsigned long long g_probe[4];
+constexpr int kProbeSlots = 65536;
+__device__ unsigned long long g_probe[kProbeSlots * 8];   // one record per workgroup (wave 0): no atomics in the timed path
 #endif
 
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
@@ -98,8 +100,12 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
-  int* tab = reinterpret_cast<int*>(smem);
-  char* stages = smem + ((T_taps * BM * 4 + 15) & ~15);
+  int* tab = reinterpret_cast<int*>(smem);                    // [T_taps][BM] gathered input pixel (or -1)
+  int2* rinfo = reinterpret_cast<int2*>(smem + ((T_taps * BM * 4 + 15) & ~15));   // [BM] {sample or -1, ho << 16 | wo}
+  char* stages = reinterpret_cast<char*>(rinfo + BM);
+#ifdef P2PHD_PROBE
+  const unsigned long long pr_t0 = __builtin_readcyclecounter();
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -113,24 +119,32 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   const int p_end = flat ? d.N * npix : npix;                 // rows >= p_end are padding
   const int n0 = blockIdx.y * BN;
 
-  {  // gather table: input pixel index (or -1) per (tap, tile row)
+  {  // row table (the only integer divisions of the kernel: one or two per tile row), then the gather table
+    // input pixel index (or -1) per (tap, tile row): each thread walks its row's taps with counters
     const int Hin = d.Hin, Win = d.Win, sh = d.sh, sw = d.sw, ntw = d.ntw, pad_mode = d.pad_mode;
     const int dh0 = d.dh0, dhs = d.dh_step, dw0 = d.dw0, dws = d.dw_step;
-    for (int e = tid; e < T_taps * BM; e += NT) {
-      const int t = e / BM, r = e - t * BM;
-      int p = p_base + r;
+    const int r = tid % BM;
+    int p = p_base + r, nn = -1, ho = 0, wo = 0;
+    if (p < p_end) {
+      nn = n;
+      if (flat) { nn = p / npix; p -= nn * npix; }
+      ho = p / Wg; wo = p - ho * Wg;
+    }
+    if (tid < BM) rinfo[r] = make_int2(nn, (ho << 16) | wo);
+    constexpr int TPR = NT / BM;                              // threads per row (2)
+    int ta = 0, tb = tid / BM;
+    while (tb >= ntw) { tb -= ntw; ++ta; }
+    for (int t = tid / BM; t < T_taps; t += TPR) {
       int off = -1;
-      if (p < p_end) {
-        int nn = n;
-        if (flat) { nn = p / npix; p -= nn * npix; }
-        const int ho = p / Wg, wo = p - ho * Wg;
-        const int ta = t / ntw, tb = t - ta * ntw;
+      if (nn >= 0) {
         int hi = ho * sh + dh0 + ta * dhs;
         int wi = wo * sw + dw0 + tb * dws;
         if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
         if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (nn * Hin + hi) * Win + wi;
       }
-      tab[e] = off;
+      tab[t * BM + r] = off;
+      tb += TPR;
+      while (tb >= ntw) { tb -= ntw; ++ta; }
     }
   }
   __syncthreads();
@@ -293,6 +307,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   int pend_slot = 0, pend_tile = 0;
 #ifdef P2PHD_PROBE
   unsigned long long pr_wait = 0, pr_bar = 0, pr_comp = 0;
+  const unsigned long long pr_t1 = __builtin_readcyclecounter();
 #endif
   for (int s = 0; s < nsteps; ++s) {
     const unsigned so = (unsigned)(cur * STAGE);
@@ -356,56 +371,64 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     cur = nslot;
   }
 #ifdef P2PHD_PROBE
-  if (lane == 0) {
-    atomicAdd(&g_probe[0], pr_wait); atomicAdd(&g_probe[1], pr_bar); atomicAdd(&g_probe[2], pr_comp);
-    atomicAdd(&g_probe[3], (unsigned long long)nsteps);
-  }
+  const unsigned long long pr_t2 = __builtin_readcyclecounter();
 #endif
   __syncthreads();
 
   // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
   constexpr int CROW = BN * (int)sizeof(T) + 16;            // padded C-tile row
   char* ct = stages;
+  // the activation is chosen ONCE per tile (a per-element switch costs a dozen scalar branches per value and keeps
+  // the tanh expansion in every element's path): a straight-line instance for tanh, one for the slope family
+  const float neg_slope = act == P2PHD_ACT_RELU ? 0.f : (act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+  auto stage_tile = [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-  for (int j = 0; j < NR; ++j) {
-    const int col = wn * (NR * 32) + j * 32 + lr;
-    int k = n0 + col;
-    if (cls_cp > 0) k = k < n_extent ? k % cls_cp : Kout;      // merged sub-pixel classes share bias / statistics of channel k
-    const float bv = (bias != nullptr && k < Kout) ? bias[k] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < NR; ++j) {
+      const int col = wn * (NR * 32) + j * 32 + lr;
+      int k = n0 + col;
+      if (cls_cp > 0) {                                        // merged sub-pixel classes share bias / statistics of channel k
+        if (k >= n_extent) k = Kout;
+        else k -= ((k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp)) * cls_cp;
+      }
+      const float bv = (bias != nullptr && k < Kout) ? bias[k] : 0.f;
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MR; ++i) {
+      for (int i = 0; i < MR; ++i) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        float v = acc[i][j][e] + bv;
-        if (p_base + row < p_end) { s1 += v; s2 += v * v; }
-        v = apply_act(v, act);
-        *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
+        for (int e = 0; e < 16; ++e) {
+          const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          float v = acc[i][j][e] + bv;
+          if (p_base + row < p_end) { s1 += v; s2 += v * v; }
+          if constexpr (ACT == P2PHD_ACT_TANH) v = tanhf(v);
+          else v = v > 0.f ? v : neg_slope * v;                // none / ReLU / LeakyReLU(0.2) as one select
+          *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
+        }
+      }
+      if (stats != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0 && k < Kout) {
+          atomicAdd(&stats[2 * ((size_t)n * Cp_out + k)], s1);
+          atomicAdd(&stats[2 * ((size_t)n * Cp_out + k) + 1], s2);
+        }
       }
     }
-    if (stats != nullptr) {
-      s1 += __shfl_xor(s1, 32);
-      s2 += __shfl_xor(s2, 32);
-      if (lh == 0 && k < Kout) {
-        atomicAdd(&stats[2 * ((size_t)n * Cp_out + k)], s1);
-        atomicAdd(&stats[2 * ((size_t)n * Cp_out + k) + 1], s2);
-      }
-    }
-  }
+  };
+  if (act == P2PHD_ACT_TANH) stage_tile(std::integral_constant<int, P2PHD_ACT_TANH>{});
+  else stage_tile(std::integral_constant<int, P2PHD_ACT_NONE>{});
   __syncthreads();
   constexpr int CPR = BN / EPP;                              // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
-    int p = p_base + row;
     int k = n0 + pc * EPP;
-    if (p >= p_end || k >= n_extent) continue;
-    int nn = n;
-    if (flat) { nn = p / npix; p -= nn * npix; }
-    int ho = p / Wg, wo = p - ho * Wg;
+    const int2 ri = rinfo[row];
+    if (ri.x < 0 || k >= n_extent) continue;
+    const int nn = ri.x;
+    int ho = ri.y >> 16, wo = ri.y & 0xFFFF;
     if (cls_cp > 0) {                                          // class (pi,pj) -> output pixel (2 ho + pi, 2 wo + pj)
-      const int cls = k / cls_cp;
+      const int cls = (k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp);
       k -= cls * cls_cp;
       ho = 2 * ho + (cls >> 1); wo = 2 * wo + (cls & 1);
       if (ho >= Hout || wo >= Wout) continue;
@@ -421,6 +444,18 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     }
     *reinterpret_cast<uint4*>(out + opix * Cp_out + k) = v;
   }
+#ifdef P2PHD_PROBE
+#ifdef P2PHD_PROBE_DRAIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // include the completion of this tile's stores
+#endif
+  const unsigned long long pr_t3 = __builtin_readcyclecounter();
+  if (tid == 0) {
+    const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x) % kProbeSlots;
+    unsigned long long* r = g_probe + (size_t)wg * 8;
+    r[0] += pr_wait; r[1] += pr_bar; r[2] += pr_comp; r[3] += (unsigned long long)nsteps;
+    r[4] += pr_t1 - pr_t0; r[5] += pr_t3 - pr_t2; r[6] += 1ull; r[7] += pr_t3 - pr_t0;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -611,58 +646,97 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     tg_off[j] = (unsigned)(TILEA + (nb / CPP) * PANEL + (8 * hh + q4) * 128 + (((((nb % CPP) >> 3) + (u8 >> 1)) ^ swzq) << 4) + 8 * (u8 & 1));
   }
 
-  auto compute = [&](int slot_, bool pf, int pf_slot) {
-    if (pf) prepare();
-    if constexpr (SZ == 2) {
-      const unsigned so = sbase + (unsigned)(slot_ * STAGE);
-      uint2 af[2][MI][2], gf[2][NI][2];
-      auto read_frags = [&](int sub, int buf) {
+  if constexpr (SZ == 2) {
+    // Same pipeline as gconv_kernel's main loop: one barrier per K step, in front of its last MFMA cluster; the next
+    // tile's first fragments and the LDS-DMA of tile s + NSTAGE (into the slot just drained) go out in the MFMA shadow.
+    uint2 af[2][MI][2], gf[2][NI][2];
+    auto read_frags = [&](unsigned so, int sub, int buf) {
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-          const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * RPA);
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][0]) : "v"(ad));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * RPA));
-        }
+      for (int i = 0; i < MI; ++i) {
+        const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * RPA);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][0]) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * RPA));
+      }
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-          const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * 128);
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][0]) : "v"(ad));
-          asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * 128));
-        }
-      };
-      read_frags(0, 0);
+      for (int j = 0; j < NI; ++j) {
+        const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * 128);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][0]) : "v"(ad));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * 128));
+      }
+    };
+    auto mfma_one = [&](int buf, int i, int j) {
+      bf16x8 a8, g8;
+      uint2* ap = reinterpret_cast<uint2*>(&a8);
+      uint2* gp = reinterpret_cast<uint2*>(&g8);
+      ap[0] = af[buf][i][0]; ap[1] = af[buf][i][1];
+      gp[0] = gf[buf][j][0]; gp[1] = gf[buf][j][1];
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, g8, acc[i][j], 0, 0, 0);
+    };
+    constexpr int NSUB = BKP / 16;
 #pragma unroll
-      for (int sub = 0; sub < BKP / 16; ++sub) {
+    for (int t = 0; t < NSTAGE; ++t) {
+      if (t < nsteps) {
+        prepare();
+#pragma unroll
+        for (int j = 0; j < NLOADS; ++j) issue_piece(t, j);
+      }
+    }
+    if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(sbase, 0, 0);
+    int cur = 0;
+    bool pend = false;
+    int pend_slot = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      const unsigned so = sbase + (unsigned)(cur * STAGE);
+      const int nslot = cur == NSTAGE - 1 ? 0 : cur + 1;
+      const bool has_next = s + 1 < nsteps;
+      const bool issue_new = s + NSTAGE < nsteps;
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
         const int buf = sub & 1;
-        if (pf) {
-#pragma unroll
-          for (int j = sub; j < NLOADS; j += BKP / 16) issue_piece(pf_slot, j);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (sub == NSUB - 1 && has_next) {
+          if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
         }
-        if (sub + 1 < BKP / 16) {
-          read_frags(sub + 1, buf ^ 1);
-          if constexpr (MI + NI == 6) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");
-          else if constexpr (MI + NI == 4) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_one(buf, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sub < NSUB - 1) read_frags(so, sub + 1, buf ^ 1);
+        else if (has_next) read_frags(sbase + (unsigned)(nslot * STAGE), 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MI * NI > 1) mfma_one(buf, 1 / NI, 1 % NI);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sub == 0 && pend) {
+#pragma unroll
+          for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, j);
+          pend = false;
+        }
+        if (sub == NSUB - 1 && issue_new) {
+          prepare();
+#pragma unroll
+          for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, j);
+          pend = true; pend_slot = cur;
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-          for (int j = 0; j < NI; ++j) {
-            bf16x8 a8, g8;
-            uint2* ap = reinterpret_cast<uint2*>(&a8);
-            uint2* gp = reinterpret_cast<uint2*>(&g8);
-            ap[0] = af[buf][i][0]; ap[1] = af[buf][i][1];
-            gp[0] = gf[buf][j][0]; gp[1] = gf[buf][j][1];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, g8, acc[i][j], 0, 0, 0);
-          }
+          for (int j = 0; j < NI; ++j)
+            if (i * NI + j >= (MI * NI > 1 ? 2 : 1)) mfma_one(buf, i, j);
         __builtin_amdgcn_sched_barrier(0);
       }
-    } else {
-      // f32 (parity runs): plain LDS reads; hipcc drains the DMA queue in front of them, which is correct, just slower
+      cur = nslot;
+    }
+  } else {
+    // f32 (parity runs): plain LDS reads; hipcc drains the DMA queue in front of them, which is correct, just slower
+    auto compute = [&](int slot_, bool pf, int pf_slot) {
       if (pf) {
+        prepare();
 #pragma unroll
         for (int j = 0; j < NLOADS; ++j) issue_piece(pf_slot, j);
       }
@@ -689,32 +763,26 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
           for (int j = 0; j < NI; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], gf[j], acc[i][j], 0, 0, 0);
       }
-    }
-  };
-
-  constexpr int D = NSTAGE - 1;
+    };
+    constexpr int D = NSTAGE - 1;
 #pragma unroll
-  for (int t = 0; t < D; ++t) {
-    if (t < nsteps) {
-      prepare();
+    for (int t = 0; t < D; ++t) {
+      if (t < nsteps) {
+        prepare();
 #pragma unroll
-      for (int j = 0; j < NLOADS; ++j) issue_piece(t, j);
+        for (int j = 0; j < NLOADS; ++j) issue_piece(t, j);
+      }
     }
-  }
-  int cur = 0, nxt = D;
-  for (int s = 0; s < nsteps; ++s) {
-    if (D >= 2 && s + 1 < nsteps) {
-      if constexpr (NLOADS == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else if constexpr (NLOADS == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0, nxt = D;
+    for (int s = 0; s < nsteps; ++s) {
+      if (D >= 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLOADS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur, s + D < nsteps, nxt);
+      cur = cur == NSTAGE - 1 ? 0 : cur + 1;
+      nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
     }
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    compute(cur, s + D < nsteps, nxt);
-    cur = cur == NSTAGE - 1 ? 0 : cur + 1;
-    nxt = nxt == NSTAGE - 1 ? 0 : nxt + 1;
   }
 
   float* slab = dwp + (size_t)blockIdx.z * slab_elems;
@@ -883,7 +951,7 @@ int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float
                      float* stats, hipStream_t st) {
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int CT = BM * (BN * (int)sizeof(T) + 16);
-  const int tab = (d.nth * d.ntw * BM * 4 + 15) & ~15;
+  const int tab = ((d.nth * d.ntw * BM * 4 + 15) & ~15) + BM * 8;        // gather table + row table
   const size_t lds = tab + (size_t)(NSTAGE * STAGE > CT ? NSTAGE * STAGE : CT);
   auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE>;
   if (lds > 64 * 1024)
@@ -910,7 +978,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // fill them, the grid still covers the chip, and ring + gather table fit the 160 KiB of LDS
   d.flat_m = stats == nullptr && (npix % 256 != 0);          // no InstanceNorm sums wanted: tiles may straddle samples
   const long mt256 = d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N;
-  const long tabb = (long)taps * 256 * 4 + 16;
+  const long tabb = (long)taps * 256 * 4 + 16 + 256 * 8;
   const long kLds = 160 * 1024;
   const bool enough_px = d.flat_m ? (long)d.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048));
   // 256 x 256 tiles (8 waves of 128 x 64, 2-slot ring): twice the MFMA work per LDS-DMA piece; for wide layers whose
@@ -937,6 +1005,11 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
     if (c192 < c256 && 2 * 448 * kRowBytes + tabb <= kLds)
       return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
   }
+  // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
+  // where 128-wide tiles would gather the A operand once more and pad the last tile
+  if (!huge && force == 0 && sizeof(T) == 2 && enough_px && !short_k && k % 192 == 0 && k <= 384 &&
+      2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
+    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
   if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st);
   if (big && bn == 128) {
     if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
@@ -1109,11 +1182,15 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hi
 }  // namespace p2phd
 
 #ifdef P2PHD_PROBE
-extern "C" int p2phd_debug_probe(unsigned long long* out4, int reset) {
-  if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 4) != hipSuccess) return -1;
+extern "C" int p2phd_debug_probe(unsigned long long* out8, int reset) {
+  static unsigned long long host[kProbeSlots * 8];
+  if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), sizeof(host)) != hipSuccess) return -1;
+  for (int k = 0; k < 8; ++k) out8[k] = 0;
+  for (int i = 0; i < kProbeSlots; ++i)
+    for (int k = 0; k < 8; ++k) out8[k] += host[(size_t)i * 8 + k];
   if (reset) {
-    unsigned long long z[4] = {0, 0, 0, 0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)) != hipSuccess) return -1;
+    void* dp = nullptr;
+    if (hipGetSymbolAddress(&dp, HIP_SYMBOL(g_probe)) != hipSuccess || hipMemset(dp, 0, sizeof(host)) != hipSuccess) return -1;
   }
   return 0;
 }

@@ -6,8 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pix2pixhdaudiosr_amd import _ops, _lib
 
-def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=5, iters=10):
-    spec = _ops.ConvSpec(cin, cout, k, 1, pad, pad_mode, False, 0, True, _ops.ACT_RELU)
+def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=5, iters=10, stride=1, transposed=False, opad=0):
+    spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, transposed, opad, True, _ops.ACT_RELU)
     x = torch.randn(batch, H, W, _ops.cpitch(cin), device="cuda").to(torch.bfloat16)
     w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
     d = spec.desc(batch, H, W, torch.bfloat16)
@@ -18,9 +18,9 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
     L = _ops.lib()
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), None, _ops.stream_ptr()))
     flops = 2.0 * batch * Ho * Wo * cin * cout * k * k
-    res = {128: [], 256: [], 512: []}
+    res = {0: [], 128: [], 256: [], 512: []}
     for r in range(rounds):
-        for bm in (128, 256, 512):
+        for bm in (0, 128, 256, 512):
             _lib.check(L.p2phd_set_option(b"gconv_bm", bm))
             call(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,6 +35,12 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
         print(f"cin{cin} cout{cout} {H}x{W} k{k} B{batch}: BM={bm}: median {v[len(v)//2]:.1f} us  min {v[0]:.1f} us  -> {flops / v[len(v)//2] / 1e6:.0f} TFLOP/s")
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "outer":
+        run(cin=48, cout=96, H=512, W=256, k=3, pad=1, pad_mode=0, stride=2, rounds=3, iters=5)
+        run(cin=96, cout=192, H=256, W=128, k=3, pad=1, pad_mode=0, stride=2, rounds=3, iters=5)
+        run(cin=192, cout=96, H=128, W=64, k=3, pad=1, pad_mode=0, stride=2, transposed=True, opad=1, rounds=3, iters=5)
+        run(cin=96, cout=48, H=256, W=128, k=3, pad=1, pad_mode=0, stride=2, transposed=True, opad=1, rounds=3, iters=5)
+        sys.exit(0)
     run()
     run(cin=384, cout=768, H=64, W=32, k=3, pad=1, pad_mode=0)
     run(cin=256, cout=512, H=65, W=33, k=4, pad=2, pad_mode=0)
