@@ -805,21 +805,38 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 // weight packing: master f32 tensor (generic strides) -> Wp[rows_pad][KK] of T, zero padded
 // and the inverse for gradients (packed f32 -> master layout, overwrite)
 // ------------------------------------------------------------------------------------------------------
+// One thread owns one (packed row, channel) pair and walks the taps with counters: its master-tensor reads are the
+// contiguous R*S block of that pair (consecutive lanes = consecutive channels, so a wave covers one contiguous span), its
+// packed writes are channel-contiguous per tap.  No integer division per element; block = 64 channels x 4 rows.
 template <typename T>
-__global__ void pack_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp, int rows_pad) {
-  const long total = (long)rows_pad * d.KK;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int row = (int)(e / d.KK);
-    const int kk = (int)(e - (long)row * d.KK);
-    const int t = kk / d.Cp_in, c = kk - t * d.Cp_in;
-    float v = 0.f;
-    if (row < m.rows && t < d.nth * d.ntw && c < m.inner) {
-      const int ta = t / d.ntw, tb = t - ta * d.ntw;
-      const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
-      v = w[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s];
+__global__ __launch_bounds__(256) void pack_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp,
+                                                   int rows_pad) {
+  const int row = blockIdx.y * 4 + threadIdx.y;
+  if (row >= rows_pad) return;
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK, ntw = d.ntw;
+  T* orow = wp + (size_t)row * KK;
+  const bool row_ok = row < m.rows;
+  const long roff = row_ok ? (long)(row % m.row_mod) * m.s_row + (long)(row / m.row_mod) * m.s_rowq : 0;
+  for (int c = blockIdx.x * 64 + threadIdx.x; c < Cp; c += gridDim.x * 64) {
+    const bool ok = row_ok && c < m.inner;
+    const float* src = w + roff + (ok ? (long)(c % m.c_mod) * m.s_inner + (long)(c / m.c_mod) * m.s_innerq : 0);
+    int ta = 0, tb = 0;
+    for (int t0 = 0; t0 < T_taps; t0 += 16) {                   // 16 independent (clamped, unconditional) loads in flight
+      float v[16];
+      int ta2 = ta, tb2 = tb;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] = src[(d.wr0 + ta2 * d.wr_step) * m.S + d.ws0 + tb2 * d.ws_step];
+        if (t0 + i + 1 < T_taps && ++tb2 == ntw) { tb2 = 0; ++ta2; }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (t0 + i < T_taps) orow[(t0 + i) * Cp + c] = from_f<T>(ok ? v[i] : 0.f);
+      ta = ta2; tb = tb2;                                       // = tap t0 + 16 when there is another batch
     }
-    wp[e] = from_f<T>(v);
   }
+  // zero tail of the padded K extent
+  for (int kk = T_taps * Cp + blockIdx.x * 64 + threadIdx.x; kk < KK; kk += gridDim.x * 64) orow[kk] = from_f<T>(0.f);
 }
 
 // Packed weights of a merged sub-pixel launch (stride 2, transposed form):
@@ -845,21 +862,35 @@ __global__ void pack_merged_kernel(GDesc d, const float* __restrict__ w, T* __re
   }
 }
 
-__global__ void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp, float* __restrict__ dw, int splits,
-                                   long slab_elems) {
-  const int T_taps = d.nth * d.ntw;
-  const long total = (long)m.rows * T_taps * m.inner;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(e % m.inner);
-    const long r2 = e / m.inner;
-    const int t = (int)(r2 % T_taps);
-    const int row = (int)(r2 / T_taps);
-    const int ta = t / d.ntw, tb = t - ta * d.ntw;
-    const int r = d.wr0 + ta * d.wr_step, s = d.ws0 + tb * d.ws_step;
-    const float* src = dwp + (size_t)row * d.KK + t * d.Cp_in + c;
-    float v = 0.f;
-    for (int z = 0; z < splits; ++z) v += src[(size_t)z * slab_elems];        // fixed order: reproducible
-    dw[(row % m.row_mod) * m.s_row + (row / m.row_mod) * m.s_rowq + (c % m.c_mod) * m.s_inner + (c / m.c_mod) * m.s_innerq + r * m.S + s] = v;
+__global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp,
+                                                          float* __restrict__ dw, int splits, long slab_elems) {
+  // same ownership as pack_kernel: thread = (row, channel), taps walked with counters; the split slabs are summed in
+  // a fixed order (reproducible), reads are channel-contiguous, the R*S results of a pair land in one contiguous block
+  const int row = blockIdx.y * 4 + threadIdx.y;
+  if (row >= m.rows) return;
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, ntw = d.ntw;
+  const float* srow = dwp + (size_t)row * d.KK;
+  const long roff = (long)(row % m.row_mod) * m.s_row + (long)(row / m.row_mod) * m.s_rowq;
+  for (int c = blockIdx.x * 64 + threadIdx.x; c < m.inner; c += gridDim.x * 64) {
+    float* dst = dw + roff + (long)(c % m.c_mod) * m.s_inner + (long)(c / m.c_mod) * m.s_innerq;
+    int ta = 0, tb = 0;
+    for (int t0 = 0; t0 < T_taps; t0 += 16) {                   // 16 taps at a time: that many independent loads in flight
+      float v[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = 0.f;
+      for (int z = 0; z < splits; ++z) {
+        const float* src = srow + (size_t)z * slab_elems + c;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] += src[(size_t)min(t0 + i, T_taps - 1) * Cp];      // unconditional, clamped
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (t0 + i < T_taps) {
+          dst[(d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step] = v[i];
+          if (++tb == ntw) { tb = 0; ++ta; }
+        }
+      }
+    }
   }
 }
 
@@ -1122,9 +1153,10 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
     return P2PHD_EUNSUPPORTED;
   }
   if (int rc = check_launch("wgrad")) return rc;
-  const long total = (long)m.rows * d.nth * d.ntw * m.inner;
-  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(unpack_grad_kernel, dim3(blocks), dim3(256), 0, st, d, m, dwp, dw, splits, slab);
+  if (m.rows > 0 && m.inner > 0) {
+    const dim3 grid((unsigned)std::min((m.inner + 63) / 64, 64), (unsigned)((m.rows + 3) / 4));
+    hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab);
+  }
   return check_launch("unpack_grad");
 }
 
@@ -1140,12 +1172,12 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
 }
 
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
-  const long total = (long)rows_pad * d.KK;
-  const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+  if (rows_pad <= 0) return P2PHD_OK;
+  const dim3 grid((unsigned)std::min((d.Cp_in + 63) / 64, 64), (unsigned)((rows_pad + 3) / 4));
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(pack_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
+    hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(64, 4), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
   else
-    hipLaunchKernelGGL(pack_kernel<float>, dim3(blocks), dim3(256), 0, st, d, m, w, (float*)wp, rows_pad);
+    hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
   return check_launch("pack_weights");
 }
 

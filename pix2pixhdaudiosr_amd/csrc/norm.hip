@@ -68,21 +68,21 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
   ChanConsts<T> cc;
   cc.load(stats, n, Cp, C, pc, 1.f / (float)HW, eps);
+  // Loads are UNCONDITIONAL (indices past the plane are clamped to its last piece and the result is dropped): a
+  // predicated load compiles to a branch with its own s_waitcnt vmcnt(0), which serialises the UN loads of a thread.
   const long stride = (long)gridDim.x * 256;
+  const long last = total - 1;
   for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
     uint4 yv[UN], rv[UN];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) {
-        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
-        if (residual != nullptr) rv[u] = *reinterpret_cast<const uint4*>(residual + base + (size_t)e * EPP);
-      }
+      const long e = min(e0 + u * stride, last);
+      yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
+      if (residual != nullptr) rv[u] = *reinterpret_cast<const uint4*>(residual + base + (size_t)e * EPP);   // uniform
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long e = e0 + u * stride;
-      if (e >= total) break;
       const T* vv = reinterpret_cast<const T*>(&yv[u]);
       const T* rr = reinterpret_cast<const T*>(&rv[u]);
       uint4 ov;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
         if (residual != nullptr) f += to_f(rr[k]);
         oo[k] = from_f<T>(pc * EPP + k < C ? f : 0.f);
       }
-      *reinterpret_cast<uint4*>(out + base + (size_t)e * EPP) = ov;
+      if (e < total) *reinterpret_cast<uint4*>(out + base + (size_t)e * EPP) = ov;
     }
   }
 }
@@ -119,25 +119,24 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
 #pragma unroll
   for (int k = 0; k < EPP; ++k) a1[k] = a2[k] = 0.f;
   const long stride = (long)gridDim.x * 256;
+  const long last = total - 1;
   for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
     uint4 gv[UN], yv[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) {
-        gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
-        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
-      }
+    for (int u = 0; u < UN; ++u) {                              // unconditional, clamped (see in_act_fwd_kernel)
+      const long e = min(e0 + u * stride, last);
+      gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
+      yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (e0 + u * stride >= total) break;
+      const float live = e0 + u * stride < total ? 1.f : 0.f;
       const T* gg = reinterpret_cast<const T*>(&gv[u]);
       const T* yy = reinterpret_cast<const T*>(&yv[u]);
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
         const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
-        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        const float gp = to_f(gg[k]) * act_slope(yh, act) * live;
         a1[k] += gp; a2[k] += gp * yh;
       }
     }
@@ -183,20 +182,19 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
     }
   }
   const long stride = (long)gridDim.x * 256;
+  const long last = total - 1;
   for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
     uint4 gv[UN], yv[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) {
-        gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
-        yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
-      }
+    for (int u = 0; u < UN; ++u) {                              // unconditional, clamped (see in_act_fwd_kernel)
+      const long e = min(e0 + u * stride, last);
+      gv[u] = *reinterpret_cast<const uint4*>(g + base + (size_t)e * EPP);
+      yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const long e = e0 + u * stride;
-      if (e >= total) break;
+      const float live = e < total ? 1.f : 0.f;
       const T* gg = reinterpret_cast<const T*>(&gv[u]);
       const T* yy = reinterpret_cast<const T*>(&yv[u]);
       uint4 ov;
@@ -206,9 +204,9 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
         const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
         const float gp = to_f(gg[k]) * act_slope(yh, act);
         oo[k] = from_f<T>(cc.rstd[k] * (gp - m1[k] - yh * m2[k]));
-        bsum[k] += to_f(oo[k]);                                 // what the next kernels read, i.e. the rounded dy
+        bsum[k] += to_f(oo[k]) * live;                          // what the next kernels read, i.e. the rounded dy
       }
-      *reinterpret_cast<uint4*>(dy + base + (size_t)e * EPP) = ov;
+      if (e < total) *reinterpret_cast<uint4*>(dy + base + (size_t)e * EPP) = ov;
     }
   }
   if (db != nullptr) {
@@ -216,6 +214,108 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
     for (int k = 0; k < EPP; ++k) atomicAdd(&s_db[pc * EPP + k], bsum[k]);     // LDS atomics
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&db[c], s_db[c]);
+  }
+}
+
+// ---- backward, small planes (HW <= 32 * ITERS pixels: the residual trunk, the coarse discriminator scale) ----------
+// One launch instead of memset + reduce + apply: a workgroup owns sample n and 128 bytes of channels (8 pieces); its
+// 256 threads are 8 piece columns x 32 pixel slices and keep their g and y pieces IN REGISTERS between the reduction
+// and the apply step, so both tensors are read from HBM exactly once (3 tensor passes instead of 5).
+template <typename T, int ITERS>
+__global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restrict__ g, const T* __restrict__ y,
+                                                               const float* __restrict__ stats, T* __restrict__ dy, int HW,
+                                                               int C, int Cp, float eps, int act, float* __restrict__ db) {
+  constexpr int EPP = Elem<T>::EPP;
+  __shared__ float s_red[4][8][2 * EPP];
+  __shared__ float s_tot[8][2 * EPP];
+  const int tid = threadIdx.x, cg = tid & 7, sl = tid >> 3, wave = tid >> 6;
+  const int n = blockIdx.y, cpr = Cp / EPP;
+  const int pc = blockIdx.x * 8 + cg;
+  const bool col_ok = pc < cpr;
+  const size_t base = (size_t)n * HW * Cp + (size_t)(col_ok ? pc : 0) * EPP;
+  ChanConsts<T> cc;
+  cc.load(stats, n, Cp, C, col_ok ? pc : 0, 1.f / (float)HW, eps);
+  // every load is unconditional (rows past the plane re-read its last pixel and are masked in the arithmetic): a
+  // predicated load becomes a branch with its own s_waitcnt, which would serialise the 2 * ITERS loads of a thread
+  uint4 gv[ITERS], yv[ITERS];
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int p = min(sl + 32 * it, HW - 1);
+    gv[it] = *reinterpret_cast<const uint4*>(g + base + (size_t)p * Cp);
+    yv[it] = *reinterpret_cast<const uint4*>(y + base + (size_t)p * Cp);
+  }
+  float a[2 * EPP];
+#pragma unroll
+  for (int k = 0; k < 2 * EPP; ++k) a[k] = 0.f;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const float live = (col_ok && sl + 32 * it < HW) ? 1.f : 0.f;
+    const T* gg = reinterpret_cast<const T*>(&gv[it]);
+    const T* yy = reinterpret_cast<const T*>(&yv[it]);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
+      const float gp = to_f(gg[k]) * act_slope(yh, act) * live;
+      a[k] += gp; a[EPP + k] += gp * yh;
+    }
+  }
+  // slices of one piece column sit 8 lanes apart: reduce over lane bits 3..5, then over the 4 waves through LDS
+#pragma unroll
+  for (int k = 0; k < 2 * EPP; ++k) {
+    a[k] += __shfl_xor(a[k], 8);
+    a[k] += __shfl_xor(a[k], 16);
+    a[k] += __shfl_xor(a[k], 32);
+  }
+  if ((tid & 63) < 8) {
+#pragma unroll
+    for (int k = 0; k < 2 * EPP; ++k) s_red[wave][cg][k] = a[k];
+  }
+  __syncthreads();
+  if (tid < 8 * 2 * EPP) {
+    const int c8 = tid / (2 * EPP), k = tid % (2 * EPP);
+    s_tot[c8][k] = s_red[0][c8][k] + s_red[1][c8][k] + s_red[2][c8][k] + s_red[3][c8][k];
+  }
+  __syncthreads();
+  const float inv = 1.f / (float)HW;
+  float m1[EPP], m2[EPP], bsum[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) { m1[k] = s_tot[cg][k] * inv; m2[k] = s_tot[cg][EPP + k] * inv; bsum[k] = 0.f; }
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int p = sl + 32 * it;
+    if (col_ok && p < HW) {
+      const T* gg = reinterpret_cast<const T*>(&gv[it]);
+      const T* yy = reinterpret_cast<const T*>(&yv[it]);
+      uint4 ov;
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
+        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        oo[k] = from_f<T>(cc.rstd[k] * (gp - m1[k] - yh * m2[k]));
+        bsum[k] += to_f(oo[k]);
+      }
+      *reinterpret_cast<uint4*>(dy + base + (size_t)p * Cp) = ov;
+    }
+  }
+  if (db != nullptr) {                                          // uniform branch: all threads take it
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      bsum[k] += __shfl_xor(bsum[k], 8);
+      bsum[k] += __shfl_xor(bsum[k], 16);
+      bsum[k] += __shfl_xor(bsum[k], 32);
+    }
+    if ((tid & 63) < 8) {
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) s_red[wave][cg][k] = bsum[k];
+    }
+    __syncthreads();
+    if (tid < 8 * EPP) {
+      const int c8 = tid / EPP, k = tid % EPP;
+      const int c = (blockIdx.x * 8 + c8) * EPP + k;
+      if (c < C) atomicAdd(&db[c], s_red[0][c8][k] + s_red[1][c8][k] + s_red[2][c8][k] + s_red[3][c8][k]);
+    }
   }
 }
 
@@ -238,19 +338,18 @@ __global__ __launch_bounds__(256) void plane_stats_kernel(const T* __restrict__ 
 #pragma unroll
   for (int k = 0; k < EPP; ++k) a1[k] = a2[k] = 0.f;
   const long stride = (long)gridDim.x * 256;
+  const long last = total - 1;
   for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
     uint4 yv[UN];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const long e = e0 + u * stride;
-      if (e < total) yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)e * EPP);
-    }
+    for (int u = 0; u < UN; ++u)                                // unconditional, clamped (see in_act_fwd_kernel)
+      yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)min(e0 + u * stride, last) * EPP);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
-      if (e0 + u * stride >= total) break;
+      const float live = e0 + u * stride < total ? 1.f : 0.f;
       const T* yy = reinterpret_cast<const T*>(&yv[u]);
 #pragma unroll
-      for (int k = 0; k < EPP; ++k) { const float v = to_f(yy[k]); a1[k] += v; a2[k] += v * v; }
+      for (int k = 0; k < EPP; ++k) { const float v = to_f(yy[k]) * live; a1[k] += v; a2[k] += v * v; }
     }
   }
 #pragma unroll
@@ -451,9 +550,20 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
   if (N == 0 || HW == 0) return P2PHD_OK;
   P2PHD_REQUIRE(g && y && stats && bstats && dy, "instnorm_act_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
   if (db != nullptr) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  // small planes with enough (sample, channel block) pairs to fill the chip: single-launch register-resident variant
+  const int cblocks = (Cp / epp + 7) / 8;
+  if (HW <= 640 && (long)N * cblocks >= 128) {
+    dim3 fgrid((unsigned)cblocks, (unsigned)N);
+#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db)
+    if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 16); else P2PHD_FUSED_BWD(bf16_t, 20); }
+    else if (dtype == P2PHD_F32) { if (HW <= 512) P2PHD_FUSED_BWD(float, 16); else P2PHD_FUSED_BWD(float, 20); }
+    else { p2phd::set_error("instnorm_act_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
+#undef P2PHD_FUSED_BWD
+    return p2phd::check_launch("instnorm_act_bwd(fused)");
+  }
+  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
   dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act),
