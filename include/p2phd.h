@@ -143,6 +143,10 @@ int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const void* packe
 size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, void* workspace,
                      void* stream);
+/* Same, but dw += and db += : the gradient lands straight in the optimiser's (zeroed) flat gradient buffer, which
+ * replaces one temporary and one `grad += new` launch per parameter of autograd's AccumulateGrad. */
+int p2phd_conv_wgrad_acc(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, void* workspace,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * HBM-bound companions (csrc/norm.hip).  NHWC tensors, channel pitch = p2phd_channel_pitch(C).
@@ -157,6 +161,9 @@ int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const v
  * db (float [C], may be NULL): the conv bias gradient = column sums of dy, accumulated in the same pass. */
 int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
                            float* db, int N, int64_t HW, int C, float eps, int act, void* stream);
+/* Same, with db += instead of db = (see p2phd_conv_wgrad_acc). */
+int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                               float* db, int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */
 int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream);
 

@@ -41,8 +41,10 @@ SIGNATURES = {
     "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_wgrad_acc": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_instnorm_act_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
+    "p2phd_instnorm_act_bwd_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "p2phd_avgpool3s2_fwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2phd_avgpool3s2_bwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -29,6 +29,13 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+def _direct_grad(p):
+    """True when `p.grad` is FlatAdam's view of its flat gradient buffer (optim.py marks the parameter)."""
+    g = p.grad
+    return (getattr(p, "_p2phd_direct_grad", False) and g is not None and g.dtype == torch.float32 and g.is_contiguous()
+            and g.shape == p.shape)
+
+
 @contextlib.contextmanager
 def no_weight_grad():
     prev = _SKIP_WGRAD[0]
@@ -208,7 +215,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.skip_wgrad = _SKIP_WGRAD[0]
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
-        ctx.x, ctx.y, ctx.stats, ctx.weight = x, y, stats, weight
+        ctx.x, ctx.y, ctx.stats, ctx.weight, ctx.bias = x, y, stats, weight, bias
         return out
 
     @staticmethod
@@ -221,14 +228,20 @@ class ConvBlockFn(torch.autograd.Function):
             g = g.to(y.dtype)
         N, Ho, Wo, Cp_out = y.shape
         need_w = (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
-        gb = torch.empty((spec.cout,), dtype=torch.float32, device=y.device) if (need_w and ctx.has_bias) else None
+        # Parameters owned by FlatAdam carry their gradient as a view of its flat buffer: the kernels then add into it
+        # directly (p2phd_*_acc) and autograd gets None, which saves a temporary and a `grad += new` launch per parameter.
+        direct = need_w and _direct_grad(weight) and (not ctx.has_bias or _direct_grad(ctx.bias))
+        gb = None
+        if need_w and ctx.has_bias:
+            gb = ctx.bias.grad if direct else torch.empty((spec.cout,), dtype=torch.float32, device=y.device)
         gb_done = False
         if spec.norm:
             dy = torch.empty_like(y)
             bstats = torch.empty((N, Cp_out, 2), dtype=torch.float32, device=y.device)
             # the bias gradient (column sums of dy) rides on the apply pass
-            check(L.p2phd_instnorm_act_bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo,
-                                           spec.cout, IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd")
+            bwd = L.p2phd_instnorm_act_bwd_acc if direct else L.p2phd_instnorm_act_bwd
+            check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
+                      stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
         elif spec.act != ACT_NONE:
             dy = torch.empty_like(y)
@@ -237,10 +250,12 @@ class ConvBlockFn(torch.autograd.Function):
             dy = g
         gx = gw = None
         if need_w:
-            gw = torch.empty(weight.shape, dtype=torch.float32, device=y.device)
+            gw = weight.grad if direct else torch.empty(weight.shape, dtype=torch.float32, device=y.device)
             ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device)
-            check(L.p2phd_conv_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()),
-                  "conv_wgrad")
+            wgrad = L.p2phd_conv_wgrad_acc if direct else L.p2phd_conv_wgrad
+            check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+            if direct:
+                gw = gb = None
         if ctx.needs_input_grad[0]:
             wp = spec.packed(weight, 1, d)
             gx = torch.empty_like(x)

@@ -673,6 +673,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, g8, acc[i][j], 0, 0, 0);
     };
     constexpr int NSUB = BKP / 16;
+#ifdef P2PHD_PROBE
+    const unsigned long long pr_t0 = __builtin_readcyclecounter();
+    unsigned long long pr_wait = 0, pr_bar = 0;
+#endif
 #pragma unroll
     for (int t = 0; t < NSTAGE; ++t) {
       if (t < nsteps) {
@@ -699,9 +703,18 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         const int buf = sub & 1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (sub == NSUB - 1 && has_next) {
+#ifdef P2PHD_PROBE
+          const unsigned long long q0 = __builtin_readcyclecounter();
+#endif
           if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef P2PHD_PROBE
+          const unsigned long long q1 = __builtin_readcyclecounter();
+#endif
           __builtin_amdgcn_s_barrier();
+#ifdef P2PHD_PROBE
+          pr_wait += q1 - q0; pr_bar += __builtin_readcyclecounter() - q1;
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         mfma_one(buf, 0, 0);
@@ -732,6 +745,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       }
       cur = nslot;
     }
+#ifdef P2PHD_PROBE
+    if (tid == 0) {
+      const unsigned wg = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % kProbeSlots;
+      unsigned long long* r = g_probe + (size_t)wg * 8;
+      r[0] += pr_wait; r[1] += pr_bar; r[2] += __builtin_readcyclecounter() - pr_t0; r[3] += (unsigned long long)nsteps;
+      r[6] += 1ull;
+    }
+#endif
   } else {
     // f32 (parity runs): plain LDS reads; hipcc drains the DMA queue in front of them, which is correct, just slower
     auto compute = [&](int slot_, bool pf, int pf_slot) {
@@ -863,7 +884,7 @@ __global__ void pack_merged_kernel(GDesc d, const float* __restrict__ w, T* __re
 }
 
 __global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp,
-                                                          float* __restrict__ dw, int splits, long slab_elems) {
+                                                          float* __restrict__ dw, int splits, long slab_elems, int accumulate) {
   // same ownership as pack_kernel: thread = (row, channel), taps walked with counters; the split slabs are summed in
   // a fixed order (reproducible), reads are channel-contiguous, the R*S results of a pair land in one contiguous block
   const int row = blockIdx.y * 4 + threadIdx.y;
@@ -886,7 +907,8 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (t0 + i < T_taps) {
-          dst[(d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step] = v[i];
+          float* o = dst + (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+          *o = accumulate ? *o + v[i] : v[i];
           if (++tb == ntw) { tb = 0; ++ta; }
         }
       }
@@ -1126,7 +1148,7 @@ size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_
 }
 
 int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
-                 const void* gat, float* dwp, float* dw, hipStream_t st) {
+                 const void* gat, float* dwp, float* dw, int accumulate, hipStream_t st) {
   // dwp: wgrad_workspace_floats() floats; dw: master-layout gradient (overwritten)
   GDesc d = d_in;
   const long P = (long)d.N * d.Hg * d.Wg;
@@ -1155,7 +1177,7 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
   if (int rc = check_launch("wgrad")) return rc;
   if (m.rows > 0 && m.inner > 0) {
     const dim3 grid((unsigned)std::min((m.inner + 63) / 64, 64), (unsigned)((m.rows + 3) / 4));
-    hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab);
+    hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
   }
   return check_launch("unpack_grad");
 }
@@ -1193,8 +1215,8 @@ int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx
   return check_launch("reflect_fold");
 }
 
-int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st) {
-  (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)K, st);
+int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st) {
+  if (!accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)K, st);
   if (P == 0) return P2PHD_OK;
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   const int cpr = Cp / epp;

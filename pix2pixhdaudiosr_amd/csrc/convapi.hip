@@ -385,8 +385,8 @@ extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   return w.dwp_bytes + extra;
 }
 
-extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
-                                void* workspace, void* stream) {
+static int conv_wgrad_impl(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, int accumulate,
+                           void* workspace, void* stream) {
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(x && dy && dw && workspace, "conv_wgrad: null pointer");
   int Ho, Wo;
@@ -408,7 +408,17 @@ extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const v
   } else {
     rows_t = x; gat_t = dy;
   }
-  if (int rc = launch_wgrad(w.p.d, w.m, c->dtype, rows_t, w.Cp_r, w.M, round_up(w.M, 128), gat_t, dwp, dw, st)) return rc;
-  if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, st);
+  if (int rc = launch_wgrad(w.p.d, w.m, c->dtype, rows_t, w.Cp_r, w.M, round_up(w.M, 128), gat_t, dwp, dw, accumulate, st)) return rc;
+  if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, accumulate, st);
   return P2PHD_OK;
+}
+
+extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
+                                void* workspace, void* stream) {
+  return conv_wgrad_impl(c, x, dy, dw, db, 0, workspace, stream);
+}
+
+extern "C" int p2phd_conv_wgrad_acc(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
+                                    void* workspace, void* stream) {
+  return conv_wgrad_impl(c, x, dy, dw, db, 1, workspace, stream);
 }

@@ -47,13 +47,13 @@ int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, cons
                  void* out, float* stats, hipStream_t st);
 size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad);
 int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
-                 const void* gat, float* dwp, float* dw, hipStream_t st);
+                 const void* gat, float* dwp, float* dw, int accumulate, hipStream_t st);
 int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int rows_pad, int K, int C, int R, int S, int pad,
                        long s_k, long s_c, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);
-int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, hipStream_t st);
+int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st);
 
 int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st);
 int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,

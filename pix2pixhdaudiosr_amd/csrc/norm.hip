@@ -543,14 +543,14 @@ extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* sta
   return p2phd::check_launch("instnorm_act_fwd");
 }
 
-extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
-                                      float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
+static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                                 float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream) {
   const int Cp = (C + 7) & ~7;
   P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
   if (N == 0 || HW == 0) return P2PHD_OK;
   P2PHD_REQUIRE(g && y && stats && bstats && dy, "instnorm_act_bwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
-  if (db != nullptr) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+  if (db != nullptr && !db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   // small planes with enough (sample, channel block) pairs to fill the chip: single-launch register-resident variant
   const int cblocks = (Cp / epp + 7) / 8;
@@ -575,6 +575,16 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
              hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act, db),
              "instnorm_act_bwd");
   return p2phd::check_launch("instnorm_act_bwd(apply)");
+}
+
+extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                                      float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
+  return instnorm_act_bwd_impl(dtype, g, y, stats, bstats, dy, db, 0, N, HW, C, eps, act, stream);
+}
+
+extern "C" int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
+                                          float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
+  return instnorm_act_bwd_impl(dtype, g, y, stats, bstats, dy, db, 1, N, HW, C, eps, act, stream);
 }
 
 extern "C" int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream) {

@@ -52,6 +52,7 @@ class FlatAdam(torch.optim.Optimizer):
                 if p.grad is not None:
                     v.copy_(p.grad)
                 p.grad = v
+            p._p2phd_direct_grad = True                          # _ops.ConvBlockFn adds its weight gradients in place
 
     def zero_grad(self, set_to_none=False):
         # gradients stay views of the flat buffer; one memset instead of one per tensor
