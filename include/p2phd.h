@@ -190,6 +190,11 @@ int p2phd_loss_bwd(int kind, int dtype, const void* a, const void* b, float targ
  * (1/world_size after a summing all-reduce).  step counts from 1. */
 int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
                     float beta1, float beta2, float eps, int64_t step, float grad_scale, void* stream);
+/* Same update with the learning rate and the step counter read from DEVICE memory (lr_dev: one float; step_dev: one
+ * int64 holding the number of steps taken so far, incremented on the stream after the update): every launch argument
+ * is then constant from step to step and the whole training step can be captured into a HIP graph and replayed. */
+int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                        int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spectrogram codec (csrc/spectro.hip): Pix2PixHDModel.to_spectro / denormalize / to_audio with

@@ -53,6 +53,7 @@ SIGNATURES = {
     "p2phd_loss_fwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp]),
     "p2phd_loss_bwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
+    "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_decode": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _vp]),

@@ -29,6 +29,21 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+# parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
+# walked once per loss: Pix2PixHDModel.train_step keeps D's weights out of the generator-loss pass)
+_BWD_SKIP_WGRAD_IDS = set()
+
+
+@contextlib.contextmanager
+def backward_without_weight_grads(params):
+    ids = {id(p) for p in params}
+    _BWD_SKIP_WGRAD_IDS.update(ids)
+    try:
+        yield
+    finally:
+        _BWD_SKIP_WGRAD_IDS.difference_update(ids)
+
+
 def _direct_grad(p):
     """True when `p.grad` is FlatAdam's view of its flat gradient buffer (optim.py marks the parameter)."""
     g = p.grad
@@ -227,7 +242,8 @@ class ConvBlockFn(torch.autograd.Function):
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
         N, Ho, Wo, Cp_out = y.shape
-        need_w = (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
+        need_w = ((ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
+                  and id(weight) not in _BWD_SKIP_WGRAD_IDS)
         # Parameters owned by FlatAdam carry their gradient as a view of its flat buffer: the kernels then add into it
         # directly (p2phd_*_acc) and autograd gets None, which saves a temporary and a `grad += new` launch per parameter.
         direct = need_w and _direct_grad(weight) and (not ctx.has_bias or _direct_grad(ctx.bias))

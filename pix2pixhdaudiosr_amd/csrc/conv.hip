@@ -860,6 +860,72 @@ __global__ __launch_bounds__(256) void pack_kernel(GDesc d, p2phd::WMap m, const
   for (int kk = T_taps * Cp + blockIdx.x * 64 + threadIdx.x; kk < KK; kk += gridDim.x * 64) orow[kk] = from_f<T>(0.f);
 }
 
+// Dense variants for the common case "every tap of a plain [rows][inner][R][S] master tensor, in order" (all stride-1
+// forward packs and weight gradients, i.e. almost all of the parameter bytes): the R*S values of a (row, channel) pair
+// and of its 63 neighbours form ONE contiguous run of the master tensor, which is moved with coalesced accesses and
+// re-ordered to / from the tap-major packed layout through a small LDS tile (T_taps is coprime to the bank count or small,
+// so the strided side of the tile costs at most a few-way conflict on 16 KiB).
+template <typename T>
+__global__ __launch_bounds__(256) void pack_dense_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp,
+                                                         int rows_pad) {
+  __shared__ float tile[4][64 * 16];
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int row = blockIdx.y * 4 + ty, c0 = blockIdx.x * 64;
+  const bool row_ok = row < m.rows;
+  const int ncols = max(0, min(64, m.inner - c0));
+  if (row_ok) {
+    const float* src = w + (long)row * m.s_row + (long)c0 * T_taps;
+    for (int i = tx; i < ncols * T_taps; i += 64) tile[ty][i] = src[i];
+  }
+  __syncthreads();
+  if (row < rows_pad) {
+    T* orow = wp + (size_t)row * KK;
+    const int c = c0 + tx;
+    if (c < Cp) {
+      const bool ok = row_ok && tx < ncols;
+      for (int t = 0; t < T_taps; ++t) orow[t * Cp + c] = from_f<T>(ok ? tile[ty][tx * T_taps + t] : 0.f);
+    }
+    if (blockIdx.x == 0)
+      for (int kk = T_taps * Cp + tx; kk < KK; kk += 64) orow[kk] = from_f<T>(0.f);
+  }
+}
+
+__global__ __launch_bounds__(256) void unpack_dense_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp,
+                                                           float* __restrict__ dw, int splits, long slab_elems, int accumulate) {
+  __shared__ float tile[4][64 * 16];
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int row = blockIdx.y * 4 + ty, c0 = blockIdx.x * 64;
+  const bool row_ok = row < m.rows;
+  const int ncols = max(0, min(64, m.inner - c0));
+  if (row_ok && tx < ncols) {
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    const float* srow = dwp + (size_t)row * d.KK + c0 + tx;
+    for (int z = 0; z < splits; ++z) {                           // fixed order: reproducible
+      const float* src = srow + (size_t)z * slab_elems;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] += src[(size_t)min(i, T_taps - 1) * Cp];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (i < T_taps) tile[ty][tx * T_taps + i] = v[i];
+  }
+  __syncthreads();
+  if (row_ok) {
+    float* dst = dw + (long)row * m.s_row + (long)c0 * T_taps;
+    for (int i = tx; i < ncols * T_taps; i += 64) dst[i] = accumulate ? dst[i] + tile[ty][i] : tile[ty][i];
+  }
+}
+
+inline bool dense_map(const GDesc& d, const p2phd::WMap& m) {
+  const int T_taps = d.nth * d.ntw;
+  return T_taps <= 16 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.s_inner == T_taps && d.wr0 == 0 && d.wr_step == 1 &&
+         d.ws0 == 0 && d.ws_step == 1 && d.ntw == m.S && m.inner > 0 && m.rows > 0;
+}
+
 // Packed weights of a merged sub-pixel launch (stride 2, transposed form):
 //   Wp[(cls, k)][(dh, dw)][c] = w(k, c, r, s)  with  r = pi + pad - 2 dh,  s = pj + pad - 2 dw  (0 when outside the kernel)
 template <typename T>
@@ -1176,8 +1242,13 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
   }
   if (int rc = check_launch("wgrad")) return rc;
   if (m.rows > 0 && m.inner > 0) {
-    const dim3 grid((unsigned)std::min((m.inner + 63) / 64, 64), (unsigned)((m.rows + 3) / 4));
-    hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+    if (dense_map(d, m)) {
+      const dim3 grid((unsigned)((m.inner + 63) / 64), (unsigned)((m.rows + 3) / 4));
+      hipLaunchKernelGGL(unpack_dense_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+    } else {
+      const dim3 grid((unsigned)std::min((m.inner + 63) / 64, 64), (unsigned)((m.rows + 3) / 4));
+      hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+    }
   }
   return check_launch("unpack_grad");
 }
@@ -1195,6 +1266,14 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
 
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
   if (rows_pad <= 0) return P2PHD_OK;
+  if (dense_map(d, m)) {
+    const dim3 dgrid((unsigned)((d.Cp_in + 63) / 64), (unsigned)((rows_pad + 3) / 4));
+    if (dtype == P2PHD_BF16)
+      hipLaunchKernelGGL(pack_dense_kernel<bf16_t>, dgrid, dim3(64, 4), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
+    else
+      hipLaunchKernelGGL(pack_dense_kernel<float>, dgrid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
+    return check_launch("pack_weights(dense)");
+  }
   const dim3 grid((unsigned)std::min((d.Cp_in + 63) / 64, 64), (unsigned)((rows_pad + 3) / 4));
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(pack_kernel<bf16_t>, grid, dim3(64, 4), 0, st, d, m, w, (bf16_t*)wp, rows_pad);

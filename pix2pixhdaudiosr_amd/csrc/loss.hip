@@ -124,6 +124,47 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 inline int grid_for(long work, int cap = 2048) { return (int)std::max<long>(1, std::min<long>((work + 255) / 256, cap)); }
 
+
+// Device-resident step counter and learning rate: the launch arguments no longer change from step to step, so a whole
+// training step (this kernel included) can be captured once into a HIP graph and replayed.
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, long n, const float* __restrict__ lr_dev,
+                                                       const long long* __restrict__ step_dev, float b1, float b2, float eps,
+                                                       float gscale) {
+  const double t = (double)(*step_dev + 1);
+  const float lr = *lr_dev;
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 256 * 4) {
+    if (e + 4 <= n) {
+      float4 pp = *reinterpret_cast<float4*>(p + e);
+      const float4 gg = *reinterpret_cast<const float4*>(g + e);
+      float4 mm = *reinterpret_cast<float4*>(m + e);
+      float4 vv = *reinterpret_cast<float4*>(v + e);
+      float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gr = ga[k] * gscale;
+        ma[k] = b1 * ma[k] + (1.f - b1) * gr;
+        va[k] = b2 * va[k] + (1.f - b2) * gr * gr;
+        pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<float4*>(p + e) = pp;
+      *reinterpret_cast<float4*>(m + e) = mm;
+      *reinterpret_cast<float4*>(v + e) = vv;
+    } else {
+      for (long i = e; i < n; ++i) {
+        const float gr = g[i] * gscale;
+        m[i] = b1 * m[i] + (1.f - b1) * gr;
+        v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
+        p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
+      }
+    }
+  }
+}
+
+__global__ void adam_tick_kernel(long long* step_dev) { *step_dev += 1; }
+
 }  // namespace
 
 extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C,
@@ -167,4 +208,18 @@ extern "C" int p2phd_adam_step(float* params, const float* grads, float* exp_avg
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
                      exp_avg_sq, (long)n, lr, beta1, beta2, eps, (float)bc1, (float)std::sqrt(bc2), grad_scale);
   return p2phd::check_launch("adam_step");
+}
+
+extern "C" int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
+                                   float grad_scale, void* stream) {
+  P2PHD_REQUIRE(n >= 0, "adam_step_dev: negative size");
+  P2PHD_REQUIRE(lr_dev && step_dev, "adam_step_dev: null state pointer");
+  if (n > 0) {
+    P2PHD_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step_dev: null pointer");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((n + 3) / 4, 4096)), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg,
+                       exp_avg_sq, (long)n, lr_dev, reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale);
+  }
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step_dev));
+  return p2phd::check_launch("adam_step_dev");
 }

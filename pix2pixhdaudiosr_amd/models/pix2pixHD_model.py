@@ -229,22 +229,30 @@ class Pix2PixHDModel(BaseModel):
     def discriminate_F(self, input_label, test_image, use_pool=False):
         return self.netD.forward(torch.cat((input_label, test_image.detach()), dim=1))
 
-    def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
+    def _losses(self, lr_audio, hr_audio, noise, share_fake_pass):
+        """All loss terms of one step.  share_fake_pass=False is the reference's schedule (pix2pixHD_model.py:331-415):
+        D(fake.detach()), D(real), D(fake).  share_fake_pass=True runs D on the generated spectrogram ONCE: the detached
+        and the attached pass compute identical values, only their backward differs, so `train_step` walks the one
+        retained graph twice (G loss without D weight gradients, then D loss restricted to D's parameters)."""
         lr_spectro, lr_pha, hr_spectro, hr_pha, _, _, hr_norm_param, lr_norm_param = \
-            self.encode_input(lr_audio, inst, hr_audio, feat, noise=noise)
+            self.encode_input(lr_audio, None, hr_audio, None, noise=noise)
 
         sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro))
         sr_result = _ops.FromPhysical.apply(sr_phys, self.opt.output_nc)
 
-        # fake detection (detached: no gradient to G), real detection
-        pred_fake_pool = self._D(lr_spectro, sr_result.detach())
-        loss_D_fake = self._gan(pred_fake_pool, 0.0)
-        pred_real = self._D(lr_spectro, hr_spectro)
-        loss_D_real = self._gan(pred_real, 1.0)
-
-        # GAN loss through D into G; D's weight gradients of this pass are never used (train.py:176)
-        with _ops.no_weight_grad():
+        if share_fake_pass:
+            pred_real = self._D(lr_spectro, hr_spectro)
             pred_fake = self._D(lr_spectro, sr_result)
+            loss_D_fake = self._gan(pred_fake, 0.0)
+        else:
+            # fake detection (detached: no gradient to G), real detection
+            pred_fake_pool = self._D(lr_spectro, sr_result.detach())
+            loss_D_fake = self._gan(pred_fake_pool, 0.0)
+            pred_real = self._D(lr_spectro, hr_spectro)
+            # GAN loss through D into G; D's weight gradients of this pass are never used (train.py:176)
+            with _ops.no_weight_grad():
+                pred_fake = self._D(lr_spectro, sr_result)
+        loss_D_real = self._gan(pred_real, 1.0)
         loss_G_GAN = self._gan(pred_fake, 1.0)
 
         loss_G_GAN_Feat = 0
@@ -268,9 +276,11 @@ class Pix2PixHDModel(BaseModel):
 
         # visuals are fetched lazily (no device->host copy in the step)
         self._visual = (lr_spectro, sr_result.detach(), hr_spectro, hr_pha)
+        return self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, loss_G_match, 0, 0, 0, loss_D_real, loss_D_fake), sr_result
 
-        return [self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, loss_G_match, 0, 0, 0, loss_D_real, loss_D_fake),
-                None if not infer else sr_result]
+    def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
+        losses, sr_result = self._losses(lr_audio, hr_audio, noise, share_fake_pass=False)
+        return [losses, None if not infer else sr_result]
 
     def inference(self, lr_audio, inst, noise=None):
         lr_spectro, lr_pha, _, _, _, _, _, lr_norm_param = self.encode_input(lr_audio, inst, None, noise=noise)
@@ -283,7 +293,7 @@ class Pix2PixHDModel(BaseModel):
     # with the D backward pass; result-identical to calling backward/step in train.py's order
     # ------------------------------------------------------------------------------------------
     def train_step(self, lr_audio, hr_audio, noise=None):
-        losses, _ = self.forward(lr_audio, None, hr_audio, None, infer=False, noise=noise)
+        losses, _ = self._losses(lr_audio, hr_audio, noise, share_fake_pass=True)
         ld = dict(zip(self.loss_names, losses))
         loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
         loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
@@ -291,14 +301,53 @@ class Pix2PixHDModel(BaseModel):
         self.optimizer_D.zero_grad()
         g_params = [p for p in self.optimizer_G._params]
         d_params = [p for p in self.optimizer_D._params]
-        # G backward: only G parameters receive gradients (inputs= keeps autograd off the D leaves)
-        loss_G.backward(inputs=g_params)
+        # G backward: only G parameters receive gradients (inputs= keeps autograd off the D leaves; D's convs skip their
+        # weight-gradient kernels in this pass).  The graph through D(fake) is kept for the D loss.
+        with _ops.backward_without_weight_grads(d_params):
+            loss_G.backward(inputs=g_params, retain_graph=True)
         self.optimizer_G.reduce_gradients_async()
         loss_D.backward(inputs=d_params)
         self.optimizer_D.reduce_gradients_async()
         self.optimizer_G.step()
         self.optimizer_D.step()
         return ld
+
+    # ------------------------------------------------------------------------------------------
+    # the same step captured once into a HIP graph and replayed: ~10^3 launches and the whole autograd walk cost
+    # no host time afterwards, so the step rate no longer depends on the host core feeding the GPU
+    # ------------------------------------------------------------------------------------------
+    def train_step_graphed(self, lr_audio, hr_audio):
+        """`train_step` through a captured graph (single GPU; with data parallelism the eager step is used, its
+        RCCL all-reduce stays outside graph capture).  Inputs are copied into static buffers; the returned loss
+        tensors are the graph's static outputs (valid until the next call).  Mask noise is drawn inside the graph."""
+        if self.optimizer_G.world_size > 1:
+            return self.train_step(lr_audio, hr_audio)
+        st = getattr(self, '_graph_state', None)
+        key = (tuple(lr_audio.shape), tuple(hr_audio.shape))
+        if st is None or st['key'] != key:
+            dev = self.device
+            st = {'key': key, 'lr': torch.empty(lr_audio.shape, dtype=torch.float32, device=dev),
+                  'hr': torch.empty(hr_audio.shape, dtype=torch.float32, device=dev), 'graph': None, 'out': None, 'calls': 0}
+            self._graph_state = st
+        st['lr'].copy_(lr_audio, non_blocking=True)
+        st['hr'].copy_(hr_audio, non_blocking=True)
+        for opt in (self.optimizer_G, self.optimizer_D):
+            opt.sync_hyper()
+        if st['graph'] is None:
+            st['calls'] += 1
+            if st['calls'] <= 2:                                   # eager steps first: workspaces, packed-weight buffers,
+                return self.train_step(st['lr'], st['hr'])          # library state all exist before capture
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st['out'] = self.train_step(st['lr'], st['hr'])
+            st['graph'] = graph
+            self.optimizer_G.step_count -= 1                       # capture records, it does not execute
+            self.optimizer_D.step_count -= 1
+        st['graph'].replay()
+        self.optimizer_G.step_count += 1
+        self.optimizer_D.step_count += 1
+        return st['out']
 
     def save(self, which_epoch):
         self.save_network(self.netG, 'G', which_epoch, self.gpu_ids)

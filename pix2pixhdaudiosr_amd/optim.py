@@ -40,6 +40,10 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = self.flat_p[o:o + n].view(p.shape)
         self._install_grad_views()
         self.step_count = 0
+        # learning rate and step counter live on the device (p2phd_adam_step_dev): a captured step replays unchanged
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._lr_pushed = None
         self.process_group = process_group
         self.world_size = 1
         self._pending = None
@@ -81,10 +85,23 @@ class FlatAdam(torch.optim.Optimizer):
             self._pending.wait()
             self._pending = None
         g = self.param_groups[0]
+        self.sync_hyper()
         self.step_count += 1
         b1, b2 = g["betas"]
-        _lib.check(_lib.lib().p2phd_adam_step(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
-                                              _lib.ptr(self.exp_avg_sq), self._total, float(g["lr"]), float(b1), float(b2),
-                                              float(g["eps"]), self.step_count, 1.0 / self.world_size, _lib.stream_ptr()),
-                   "adam_step")
+        _lib.check(_lib.lib().p2phd_adam_step_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
+                                                  _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
+                                                  _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
+                                                  1.0 / self.world_size, _lib.stream_ptr()), "adam_step")
         _ops.bump_weight_epoch()
+
+    def sync_hyper(self):
+        """Push param_groups[0]['lr'] to the device copy the kernel reads (only when it changed).  Called by step();
+        a caller that REPLAYS a captured step calls it itself before the replay."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_pushed:
+            self.lr_dev.fill_(lr)
+            self._lr_pushed = lr
+
+    def steps_taken(self):
+        """Number of updates applied so far, including replays of a captured step (device counter; synchronises)."""
+        return int(self.step_dev.item())
