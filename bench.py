@@ -148,15 +148,21 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     log(f"model built, batch {a.batch}, world {world}")
-    # One GPU: the step is captured once into a HIP graph and replayed (same kernels, same order, no host work per step).
-    # Data parallel: eager step, the RCCL all-reduce of the G gradients overlaps the D backward.
-    graphed = world == 1 and not a.no_graph
+    # The step is captured once into HIP graphs and replayed (same kernels, same order, no host work per step); with
+    # data parallelism the two RCCL all-reduces run between the replays, the G one overlapping the D backward.
+    graphed = not a.no_graph
     step = model.train_step_graphed if graphed else model.train_step
     if graphed:
-        for _ in range(3):                                         # two eager steps + capture, before the warm-up steps
-            step(lr, hr)
-        torch.cuda.synchronize()
-        log("step captured into a HIP graph")
+        try:
+            for _ in range(3):                                     # two eager steps + capture, before the warm-up steps
+                step(lr, hr)
+            torch.cuda.synchronize()
+            log("step captured into HIP graphs (forward + G backward | D backward | Adam), collectives between replays")
+        except Exception as e:                                     # keep the measurement: fall back to the eager step
+            log(f"graph capture failed ({type(e).__name__}: {e}); running the eager step")
+            graphed, step = False, model.train_step
+            model._graph_state = None
+            torch.cuda.synchronize()
     for i in range(a.warmup):
         step(lr, hr)
         torch.cuda.synchronize()

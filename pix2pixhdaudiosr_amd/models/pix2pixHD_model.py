@@ -19,6 +19,8 @@ Deliberate differences:
   * ``.module`` returns the model itself (create_model never wraps in DataParallel, see models.py).
 """
 import numpy as np
+import os
+
 import torch
 
 from .. import _lib, _ops
@@ -292,61 +294,90 @@ class Pix2PixHDModel(BaseModel):
     # one full optimisation step (train.py:148-184) with the all-reduce of the G gradients overlapped
     # with the D backward pass; result-identical to calling backward/step in train.py's order
     # ------------------------------------------------------------------------------------------
-    def train_step(self, lr_audio, hr_audio, noise=None):
+    def _phase_a(self, lr_audio, hr_audio, noise=None):
+        """Forward of G and D, all losses, zeroed gradient buffers, backward of the generator loss."""
         losses, _ = self._losses(lr_audio, hr_audio, noise, share_fake_pass=True)
         ld = dict(zip(self.loss_names, losses))
-        loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
+        self._loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
         loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
         self.optimizer_G.zero_grad()
         self.optimizer_D.zero_grad()
-        g_params = [p for p in self.optimizer_G._params]
-        d_params = [p for p in self.optimizer_D._params]
         # G backward: only G parameters receive gradients (inputs= keeps autograd off the D leaves; D's convs skip their
         # weight-gradient kernels in this pass).  The graph through D(fake) is kept for the D loss.
-        with _ops.backward_without_weight_grads(d_params):
-            loss_G.backward(inputs=g_params, retain_graph=True)
-        self.optimizer_G.reduce_gradients_async()
-        loss_D.backward(inputs=d_params)
+        with _ops.backward_without_weight_grads(self.optimizer_D._params):
+            loss_G.backward(inputs=list(self.optimizer_G._params), retain_graph=True)
+        return ld
+
+    def _phase_b(self):
+        """Backward of the discriminator loss through the graph phase A kept."""
+        loss_D, self._loss_D = self._loss_D, None
+        loss_D.backward(inputs=list(self.optimizer_D._params))
+
+    def train_step(self, lr_audio, hr_audio, noise=None):
+        ld = self._phase_a(lr_audio, hr_audio, noise)
+        self.optimizer_G.reduce_gradients_async()                   # overlaps the D backward
+        self._phase_b()
         self.optimizer_D.reduce_gradients_async()
         self.optimizer_G.step()
         self.optimizer_D.step()
         return ld
 
     # ------------------------------------------------------------------------------------------
-    # the same step captured once into a HIP graph and replayed: ~10^3 launches and the whole autograd walk cost
-    # no host time afterwards, so the step rate no longer depends on the host core feeding the GPU
+    # the same step captured once into HIP graphs and replayed: ~10^3 launches and the whole autograd walk cost no
+    # host time afterwards, so the step rate no longer depends on the host core that feeds the GPU.  Three graphs
+    # on one memory pool -- A: forward + G backward, B: D backward, C: both Adam updates -- so that with data
+    # parallelism the two RCCL all-reduces run BETWEEN replays, outside capture, the G one overlapping graph B.
     # ------------------------------------------------------------------------------------------
     def train_step_graphed(self, lr_audio, hr_audio):
-        """`train_step` through a captured graph (single GPU; with data parallelism the eager step is used, its
-        RCCL all-reduce stays outside graph capture).  Inputs are copied into static buffers; the returned loss
-        tensors are the graph's static outputs (valid until the next call).  Mask noise is drawn inside the graph."""
-        if self.optimizer_G.world_size > 1:
-            return self.train_step(lr_audio, hr_audio)
+        """`train_step` through captured graphs.  Inputs are copied into static buffers; the returned loss tensors are
+        static outputs of graph A (valid until the next call).  Mask noise is drawn inside the graph."""
         st = getattr(self, '_graph_state', None)
-        key = (tuple(lr_audio.shape), tuple(hr_audio.shape))
+        key = (tuple(lr_audio.shape), tuple(hr_audio.shape), self.optimizer_G.world_size)
         if st is None or st['key'] != key:
             dev = self.device
             st = {'key': key, 'lr': torch.empty(lr_audio.shape, dtype=torch.float32, device=dev),
-                  'hr': torch.empty(hr_audio.shape, dtype=torch.float32, device=dev), 'graph': None, 'out': None, 'calls': 0}
+                  'hr': torch.empty(hr_audio.shape, dtype=torch.float32, device=dev), 'graphs': None, 'out': None, 'calls': 0}
             self._graph_state = st
         st['lr'].copy_(lr_audio, non_blocking=True)
         st['hr'].copy_(hr_audio, non_blocking=True)
-        for opt in (self.optimizer_G, self.optimizer_D):
-            opt.sync_hyper()
-        if st['graph'] is None:
+        optG, optD = self.optimizer_G, self.optimizer_D
+        optG.sync_hyper()
+        optD.sync_hyper()
+        if st['graphs'] is None:
             st['calls'] += 1
             if st['calls'] <= 2:                                   # eager steps first: workspaces, packed-weight buffers,
                 return self.train_step(st['lr'], st['hr'])          # library state all exist before capture
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                st['out'] = self.train_step(st['lr'], st['hr'])
-            st['graph'] = graph
-            self.optimizer_G.step_count -= 1                       # capture records, it does not execute
-            self.optimizer_D.step_count -= 1
-        st['graph'].replay()
-        self.optimizer_G.step_count += 1
-        self.optimizer_D.step_count += 1
+            gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # back-to-back captures on one side stream and one pool, without the cache flush torch.cuda.graph()
+            # does on entry (blocks the first capture freed must stay where its replay will write them)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                gA.capture_begin()
+                st['out'] = self._phase_a(st['lr'], st['hr'])
+                gA.capture_end()
+                gB.capture_begin(pool=gA.pool())
+                self._phase_b()
+                gB.capture_end()
+                gC.capture_begin(pool=gA.pool())
+                optG.step_local()
+                optD.step_local()
+                gC.capture_end()
+            torch.cuda.current_stream().wait_stream(side)
+            optG.step_count -= 1                                   # capture records, it does not execute
+            optD.step_count -= 1
+            st['graphs'] = (gA, gB, gC)
+        gA, gB, gC = st['graphs']
+        gA.replay()
+        optG.reduce_gradients_async()                               # no-ops on one GPU
+        gB.replay()
+        optD.reduce_gradients_async()
+        optG.wait_gradients()
+        optD.wait_gradients()
+        gC.replay()
+        optG.step_count += 1
+        optD.step_count += 1
         return st['out']
 
     def save(self, which_epoch):

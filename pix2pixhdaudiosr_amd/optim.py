@@ -75,6 +75,12 @@ class FlatAdam(torch.optim.Optimizer):
             self._install_grad_views()
             self._pending = all_reduce_flat_async(self.flat_g, self.process_group)
 
+    def wait_gradients(self):
+        """Make the current stream wait for the gradient all-reduce started by reduce_gradients_async()."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
     @torch.no_grad()
     def step(self, closure=None):
         if closure is not None:
@@ -82,8 +88,12 @@ class FlatAdam(torch.optim.Optimizer):
         self._install_grad_views()
         if self.world_size > 1:
             self.reduce_gradients_async()
-            self._pending.wait()
-            self._pending = None
+            self.wait_gradients()
+        self.step_local()
+
+    @torch.no_grad()
+    def step_local(self):
+        """The update itself, without the data-parallel exchange (graph-capturable: every argument is constant)."""
         g = self.param_groups[0]
         self.sync_hyper()
         self.step_count += 1

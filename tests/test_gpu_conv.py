@@ -1,6 +1,8 @@
 """GPU parity of the fused conv block (HIP implicit-GEMM conv + InstanceNorm/act kernels, through the C ABI)
 against the same layer expressed with torch-CPU fp32 functional ops (the oracle's building blocks), for every
 conv geometry the generator / discriminator use: forward, input gradient, weight and bias gradients."""
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -57,7 +59,7 @@ def _oracle(x, w, b, res, c):
 def test_conv_block(case, dtype, tol):
     from pix2pixhdaudiosr_amd import _ops
     name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, (N, H, W), use_res = case
-    g = torch.Generator().manual_seed(hash(name) % 1000)
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # stable across processes (hash() is salted)
     x = torch.randn(N, cin, H, W, generator=g)
     wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
     w = torch.randn(wshape, generator=g) * 0.1

@@ -217,7 +217,7 @@ def test_graphed_step_equals_eager_step(golden_model):
         for k in la:
             va, vb = float(la[k]), float(lb[k])
             assert abs(va - vb) <= 2e-3 * max(abs(va), 1e-3), (i, k, va, vb)
-    assert b._graph_state['graph'] is not None
+    assert b._graph_state['graphs'] is not None
     assert a.optimizer_G.steps_taken() == b.optimizer_G.steps_taken() == 5
     assert b.optimizer_G.step_count == 5 and b.optimizer_D.step_count == 5
     for net_a, net_b in ((a.netG, b.netG), (a.netD, b.netD)):
