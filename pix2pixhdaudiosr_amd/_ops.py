@@ -29,6 +29,42 @@ def bump_weight_epoch():
     _WEIGHT_EPOCH[0] += 1
 
 
+# Small zero-initialised buffers (InstanceNorm statistics, scalar loss accumulators): one arena per device that the
+# model zeroes ONCE at the start of a step (`begin_step`) and hands out in slices, instead of one fill launch per
+# buffer (~60 per step).  Slices stay valid until the next begin_step(), i.e. through that step's backward.
+_ARENA = {}
+
+
+def begin_step(device, nbytes=32 << 20):
+    a = _ARENA.get(str(device))
+    if a is None or a["buf"].numel() < nbytes:
+        a = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=device), "off": 0, "live": False}
+        _ARENA[str(device)] = a
+    a["buf"].zero_()
+    a["off"], a["live"] = 0, True
+
+
+def end_arena(device):
+    """Stop handing out arena slices (buffers created afterwards are zeroed individually again)."""
+    a = _ARENA.get(str(device))
+    if a is not None:
+        a["live"] = False
+
+
+def zeros(shape, device):
+    """float32 zeros: a slice of the step arena when one is live and has room, else torch.zeros."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    a = _ARENA.get(str(device))
+    nbytes = (n * 4 + 15) & ~15
+    if a is None or not a["live"] or a["off"] + nbytes > a["buf"].numel():
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    t = a["buf"][a["off"]:a["off"] + n * 4].view(torch.float32).view(shape)
+    a["off"] += nbytes
+    return t
+
+
 # parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
 # walked once per loss: Pix2PixHDModel.train_step keeps D's weights out of the generator-loss pass)
 _BWD_SKIP_WGRAD_IDS = set()
@@ -212,7 +248,7 @@ class ConvBlockFn(torch.autograd.Function):
         wp = spec.packed(weight, 0, d)
         b = None if bias is None else bias.detach().float().contiguous()
         y = torch.empty((N, Ho, Wo, Cp_out), dtype=x.dtype, device=x.device)
-        stats = torch.zeros((N, Cp_out, 2), dtype=torch.float32, device=x.device) if spec.norm else None
+        stats = zeros((N, Cp_out, 2), x.device) if spec.norm else None
         fused_act = ACT_NONE if spec.norm else spec.act
         wsb = L.p2phd_conv_fwd_workspace_bytes(C.byref(d))
         ws = workspace(wsb, x.device) if wsb else None
@@ -325,7 +361,7 @@ class LossFn(torch.autograd.Function):
     def forward(ctx, a, b, kind, target, coeff, channels):
         a = phys(a, "loss input")
         P = a.numel() // a.shape[-1]
-        out = torch.zeros((), dtype=torch.float32, device=a.device)
+        out = zeros((), a.device)
         check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(a), ptr(b), float(target), P, channels, float(coeff),
                                    ptr(out), stream_ptr()), "loss_fwd")
         ctx.meta = (kind, float(target), float(coeff), channels, P)

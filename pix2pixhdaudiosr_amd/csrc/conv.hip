@@ -650,20 +650,38 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     // Same pipeline as gconv_kernel's main loop: one barrier per K step, in front of its last MFMA cluster; the next
     // tile's first fragments and the LDS-DMA of tile s + NSTAGE (into the slot just drained) go out in the MFMA shadow.
     uint2 af[2][MI][2], gf[2][NI][2];
+    // the k sub-step and the second half of a fragment ride on the instruction's immediate offset: one address VGPR
+    // per fragment and K step instead of one add per read (`sub` is a literal after unrolling, the switch folds away)
+#define P2PHD_TR_READ(dst, addr, OFF) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF))
+#define P2PHD_TR_PAIR(lo, hi, addr, SUB, PITCH)                                                        \
+  do {                                                                                                 \
+    P2PHD_TR_READ(lo, addr, 16 * (SUB) * (PITCH));                                                     \
+    P2PHD_TR_READ(hi, addr, 16 * (SUB) * (PITCH) + 4 * (PITCH));                                       \
+  } while (0)
     auto read_frags = [&](unsigned so, int sub, int buf) {
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const unsigned ad = so + ta_off[i] + (unsigned)(16 * sub * RPA);
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][0]) : "v"(ad));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(af[buf][i][1]) : "v"(ad + 4 * RPA));
+        const unsigned ad = so + ta_off[i];
+        switch (sub) {
+          case 0: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 0, RPA); break;
+          case 1: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 1, RPA); break;
+          case 2: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 2, RPA); break;
+          default: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 3, RPA); break;
+        }
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
-        const unsigned ad = so + tg_off[j] + (unsigned)(16 * sub * 128);
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][0]) : "v"(ad));
-        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(gf[buf][j][1]) : "v"(ad + 4 * 128));
+        const unsigned ad = so + tg_off[j];
+        switch (sub) {
+          case 0: P2PHD_TR_PAIR(gf[buf][j][0], gf[buf][j][1], ad, 0, 128); break;
+          case 1: P2PHD_TR_PAIR(gf[buf][j][0], gf[buf][j][1], ad, 1, 128); break;
+          case 2: P2PHD_TR_PAIR(gf[buf][j][0], gf[buf][j][1], ad, 2, 128); break;
+          default: P2PHD_TR_PAIR(gf[buf][j][0], gf[buf][j][1], ad, 3, 128); break;
+        }
       }
     };
+    static_assert(BKP / 16 <= 4, "sub-step switch covers 4 k sub-steps");
     auto mfma_one = [&](int buf, int i, int j) {
       bf16x8 a8, g8;
       uint2* ap = reinterpret_cast<uint2*>(&a8);
