@@ -164,8 +164,17 @@ def main():
             model._graph_state = None
             torch.cuda.synchronize()
     for i in range(a.warmup):
-        step(lr, hr)
-        torch.cuda.synchronize()
+        try:
+            step(lr, hr)
+            torch.cuda.synchronize()
+        except Exception as e:
+            if not graphed:
+                raise
+            log(f"graph replay failed in warm-up ({type(e).__name__}: {e}); running the eager step")
+            graphed, step = False, model.train_step
+            model._graph_state = None
+            step(lr, hr)
+            torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     barrier()
     t0 = time.perf_counter()

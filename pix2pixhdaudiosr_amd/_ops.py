@@ -35,18 +35,26 @@ def bump_weight_epoch():
 _ARENA = {}
 
 
+def _dev_key(device):
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return str(device)
+
+
 def begin_step(device, nbytes=32 << 20):
-    a = _ARENA.get(str(device))
+    device = _dev_key(device)
+    a = _ARENA.get(device)
     if a is None or a["buf"].numel() < nbytes:
         a = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=device), "off": 0, "live": False}
-        _ARENA[str(device)] = a
+        _ARENA[device] = a
     a["buf"].zero_()
     a["off"], a["live"] = 0, True
 
 
 def end_arena(device):
     """Stop handing out arena slices (buffers created afterwards are zeroed individually again)."""
-    a = _ARENA.get(str(device))
+    a = _ARENA.get(_dev_key(device))
     if a is not None:
         a["live"] = False
 
@@ -56,7 +64,7 @@ def zeros(shape, device):
     n = 1
     for d in shape:
         n *= int(d)
-    a = _ARENA.get(str(device))
+    a = _ARENA.get(str(device)) if _ARENA else None
     nbytes = (n * 4 + 15) & ~15
     if a is None or not a["live"] or a["off"] + nbytes > a["buf"].numel():
         return torch.zeros(shape, dtype=torch.float32, device=device)
