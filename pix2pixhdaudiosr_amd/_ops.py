@@ -244,7 +244,7 @@ class ConvSpec:
 
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec):
+    def forward(ctx, x, weight, bias, residual, spec, link=None):
         x = phys(x, "conv input")
         N, H, W, Cp_in = x.shape
         if Cp_in != cpitch(spec.cin):
@@ -275,6 +275,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.x, ctx.y, ctx.stats, ctx.weight, ctx.bias = x, y, stats, weight, bias
+        ctx.link = link
         return out
 
     @staticmethod
@@ -321,13 +322,45 @@ class ConvBlockFn(torch.autograd.Function):
             gx = torch.empty_like(x)
             wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))
             ws = workspace(wsb, y.device) if wsb else None
-            check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), None, ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
+            # first conv of a residual block: the skip gradient parked by the block's second conv is added inside the
+            # dgrad (epilogue / reflect fold) instead of by a separate autograd add
+            addend = None
+            if ctx.link is not None and ctx.link.role_of(ctx) == "a":
+                addend = ctx.link.take()
+            check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
         gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gres, None
+        if gres is not None and ctx.link is not None and ctx.link.park(gres, ctx):
+            gres = None
+        return gx, gw, gb, gres, None, None
 
 
-def conv_block(x, weight, bias, spec, residual=None):
-    return ConvBlockFn.apply(x, weight, bias, residual, spec)
+class SkipLink:
+    """Couples the two convs of one ResnetBlock call: out = x + b(a(x)).  In backward, b runs first and parks the
+    gradient of the skip path here; a (whose input is the same x) hands it to its dgrad kernel as `addend`, so the
+    sum dL/dx = dgrad_a(.) + dL/dout is formed inside that kernel.  One link per forward call of the block."""
+
+    def __init__(self):
+        self.g = None
+        self.armed = False            # set once conv `a` ran its forward with an input that needs a gradient
+
+    def role_of(self, ctx):
+        return "b" if ctx.has_res else "a"
+
+    def park(self, g, ctx):
+        if not (self.armed and ctx.has_res):
+            return False
+        self.g = g
+        return True
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
+def conv_block(x, weight, bias, spec, residual=None, link=None):
+    if link is not None and residual is None:
+        link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
+    return ConvBlockFn.apply(x, weight, bias, residual, spec, link)
 
 
 # ------------------------------------------------------------------------------------------

@@ -105,8 +105,8 @@ class _ConvStep:
     def __init__(self, conv, spec):
         self.conv, self.spec = conv, spec
 
-    def run(self, x, residual=None):
-        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual)
+    def run(self, x, residual=None, link=None):
+        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link)
 
 
 class _ResStep:
@@ -116,7 +116,8 @@ class _ResStep:
 
     def run(self, x, residual=None):
         assert residual is None
-        return self.b.run(self.a.run(x), residual=x)       # x + conv_block(x), reference networks.py:252
+        link = _ops.SkipLink()                              # skip-path gradient is added inside conv a's dgrad
+        return self.b.run(self.a.run(x, link=link), residual=x, link=link)   # x + conv_block(x), reference networks.py:252
 
 
 def _compile(seq):
