@@ -73,6 +73,11 @@ def zeros(shape, device):
     return t
 
 
+# measurement hook: `match(spec, N, H, W) -> bool` selects conv layers whose forward launch is bracketed by HIP events on
+# the launch stream (eager steps only); bench.py times the dominant kernel inside a real step this way
+_KERNEL_PROBE = {"match": None, "events": []}
+
+
 # parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
 # walked once per loss: Pix2PixHDModel.train_step keeps D's weights out of the generator-loss pass)
 _BWD_SKIP_WGRAD_IDS = set()
@@ -260,7 +265,16 @@ class ConvBlockFn(torch.autograd.Function):
         fused_act = ACT_NONE if spec.norm else spec.act
         wsb = L.p2phd_conv_fwd_workspace_bytes(C.byref(d))
         ws = workspace(wsb, x.device) if wsb else None
+        probe = _KERNEL_PROBE.get("match")
+        if probe is not None and probe(spec, N, H, W):              # bench.py: HIP events around this layer's launches
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        else:
+            e0 = None
         check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
+        if e0 is not None:
+            e1.record()
+            _KERNEL_PROBE["events"].append((e0, e1))
         if spec.norm:
             res = None if residual is None else phys(residual, "residual")
             out = torch.empty_like(y)
