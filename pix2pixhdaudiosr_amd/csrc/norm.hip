@@ -19,16 +19,14 @@ template <typename T> __device__ __forceinline__ T from_f(float v);
 template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return (bf16_t)v; }
 
-__device__ __forceinline__ float act_fwd(float v, int act) {
-  if (act == P2PHD_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == P2PHD_ACT_LRELU) return v > 0.f ? v : 0.2f * v;
-  return v;
+// The activation code is folded into ONE float per kernel (slope applied to negative pre-activations: 0 ReLU, 0.2
+// LeakyReLU, 1 none), so the per-element work is a compare + select instead of a chain of uniform branches on `act`
+// (2 branches per element and pass showed up as issue stalls in these otherwise load-bound kernels).
+__device__ __forceinline__ float neg_slope_of(int act) {
+  return act == P2PHD_ACT_RELU ? 0.f : (act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
 }
-__device__ __forceinline__ float act_slope(float v, int act) {   // derivative at pre-activation v
-  if (act == P2PHD_ACT_RELU) return v > 0.f ? 1.f : 0.f;
-  if (act == P2PHD_ACT_LRELU) return v > 0.f ? 1.f : 0.2f;
-  return 1.f;
-}
+__device__ __forceinline__ float act_fwd(float v, float neg_slope) { return v > 0.f ? v : neg_slope * v; }
+__device__ __forceinline__ float act_slope(float v, float neg_slope) { return v > 0.f ? 1.f : neg_slope; }   // at pre-activation v
 
 constexpr int kMaxCp = 4096;   // bounds the LDS partial-sum tables of the backward kernels
 
@@ -66,6 +64,7 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  const float nslope = neg_slope_of(act);
   ChanConsts<T> cc;
   cc.load(stats, n, Cp, C, pc, 1.f / (float)HW, eps);
   // Loads are UNCONDITIONAL (indices past the plane are clamped to its last piece and the result is dropped): a
@@ -89,7 +88,7 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
       T* oo = reinterpret_cast<T*>(&ov);
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
-        float f = act_fwd((to_f(vv[k]) - cc.mean[k]) * cc.rstd[k], act);
+        float f = act_fwd((to_f(vv[k]) - cc.mean[k]) * cc.rstd[k], nslope);
         if (residual != nullptr) f += to_f(rr[k]);
         oo[k] = from_f<T>(pc * EPP + k < C ? f : 0.f);
       }
@@ -113,6 +112,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  const float nslope = neg_slope_of(act);
   ChanConsts<T> cc;
   cc.load(stats, n, Cp, C, pc, 1.f / (float)HW, eps);
   float a1[EPP], a2[EPP];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
         const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
-        const float gp = to_f(gg[k]) * act_slope(yh, act) * live;
+        const float gp = to_f(gg[k]) * act_slope(yh, nslope) * live;
         a1[k] += gp; a2[k] += gp * yh;
       }
     }
@@ -169,6 +169,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  const float nslope = neg_slope_of(act);
   ChanConsts<T> cc;
   cc.load(stats, n, Cp, C, pc, inv, eps);
   float m1[EPP], m2[EPP], bsum[EPP];
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
         const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
-        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        const float gp = to_f(gg[k]) * act_slope(yh, nslope);
         oo[k] = from_f<T>(cc.rstd[k] * (gp - m1[k] - yh * m2[k]));
         bsum[k] += to_f(oo[k]) * live;                          // what the next kernels read, i.e. the rounded dy
       }
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
   const int pc = blockIdx.x * 8 + cg;
   const bool col_ok = pc < cpr;
   const size_t base = (size_t)n * HW * Cp + (size_t)(col_ok ? pc : 0) * EPP;
+  const float nslope = neg_slope_of(act);
   ChanConsts<T> cc;
   cc.load(stats, n, Cp, C, col_ok ? pc : 0, 1.f / (float)HW, eps);
   // every load is unconditional (rows past the plane re-read its last pixel and are masked in the arithmetic): a
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
 #pragma unroll
     for (int k = 0; k < EPP; ++k) {
       const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
-      const float gp = to_f(gg[k]) * act_slope(yh, act) * live;
+      const float gp = to_f(gg[k]) * act_slope(yh, nslope) * live;
       a[k] += gp; a[EPP + k] += gp * yh;
     }
   }
@@ -291,7 +293,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
         const float yh = (to_f(yy[k]) - cc.mean[k]) * cc.rstd[k];
-        const float gp = to_f(gg[k]) * act_slope(yh, act);
+        const float gp = to_f(gg[k]) * act_slope(yh, nslope);
         oo[k] = from_f<T>(cc.rstd[k] * (gp - m1[k] - yh * m2[k]));
         bsum[k] += to_f(oo[k]);
       }
