@@ -166,6 +166,10 @@ int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const fl
                                float* db, int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */
 int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream);
+/* Same over [n_pixels][Cp] tensors, plus db[c] (+)= sum over pixels of dx[., c]: the conv bias gradient of a layer with a
+ * fused activation and no norm (networks.py:342-343), without a second read of dx. */
+int p2phd_act_bwd_db(int dtype, const void* g, const void* a, void* dx, int64_t n_pixels, int C, int act, float* db,
+                     int db_accumulate, void* stream);
 
 /* nn.AvgPool2d(3, stride=2, padding=[1,1], count_include_pad=False) (networks.py:165,308). */
 int p2phd_avgpool3s2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);

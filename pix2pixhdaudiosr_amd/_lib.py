@@ -46,6 +46,7 @@ SIGNATURES = {
     "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "p2phd_act_bwd_db": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "p2phd_avgpool3s2_fwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2phd_avgpool3s2_bwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2phd_nchw_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),

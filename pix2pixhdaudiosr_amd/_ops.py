@@ -320,7 +320,12 @@ class ConvBlockFn(torch.autograd.Function):
             gb_done = gb is not None
         elif spec.act != ACT_NONE:
             dy = torch.empty_like(y)
-            check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
+            if gb is not None:                                     # bias gradient rides on the activation-backward pass
+                check(L.p2phd_act_bwd_db(d.dtype, ptr(g), ptr(y), ptr(dy), N * Ho * Wo, spec.cout, spec.act, ptr(gb),
+                                         1 if direct else 0, stream_ptr()), "act_bwd_db")
+                gb_done = True
+            else:
+                check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
         else:
             dy = g
         gx = gw = None

@@ -387,6 +387,57 @@ __global__ void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a,
   }
 }
 
+// Same, channel-stationary, with the conv bias gradient (column sums of the rounded dx) accumulated in the same pass:
+// saves the separate column-sum read of dx for the discriminator layers that have a fused activation and no norm.
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_db_kernel(const T* __restrict__ g, const T* __restrict__ a, T* __restrict__ dx,
+                                                         long P, int C, int Cp, int act, float* __restrict__ db) {
+  constexpr int EPP = Elem<T>::EPP;
+  constexpr int UN = 4;
+  extern __shared__ float s_db[];                               // [Cp]
+  for (int c = threadIdx.x; c < Cp; c += 256) s_db[c] = 0.f;
+  __syncthreads();
+  const int cpr = Cp / EPP;
+  const long total = P * cpr, last = total - 1;
+  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  const float nslope = neg_slope_of(act);
+  const bool is_tanh = act == P2PHD_ACT_TANH;
+  float bsum[EPP];
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) bsum[k] = 0.f;
+  const long stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
+    uint4 gv[UN], av[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {                              // unconditional, clamped (see in_act_fwd_kernel)
+      const long e = min(e0 + u * stride, last);
+      gv[u] = *reinterpret_cast<const uint4*>(g + (size_t)e * EPP);
+      av[u] = *reinterpret_cast<const uint4*>(a + (size_t)e * EPP);
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const long e = e0 + u * stride;
+      const float live = e < total ? 1.f : 0.f;
+      const T* gg = reinterpret_cast<const T*>(&gv[u]);
+      const T* aa = reinterpret_cast<const T*>(&av[u]);
+      uint4 ov;
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) {
+        const float o = to_f(aa[k]);
+        const float s = is_tanh ? 1.f - o * o : (o > 0.f ? 1.f : nslope);
+        oo[k] = from_f<T>(to_f(gg[k]) * s);
+        bsum[k] += to_f(oo[k]) * live;
+      }
+      if (e < total) *reinterpret_cast<uint4*>(dx + (size_t)e * EPP) = ov;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < EPP; ++k) atomicAdd(&s_db[pc * EPP + k], bsum[k]);
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&db[c], s_db[c]);
+}
+
 // ---- AvgPool2d(3, stride 2, pad 1, count_include_pad=False) -------------------------------------------
 template <typename T>
 __global__ void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int Ho, int Wo, int Cp) {
@@ -655,4 +706,23 @@ extern "C" int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N,
              hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)src, dst, N, C, (long)HW, Cp, ch_off),
              "nhwc_to_nchw");
   return p2phd::check_launch("nhwc_to_nchw");
+}
+
+extern "C" int p2phd_act_bwd_db(int dtype, const void* g, const void* a, void* dx, int64_t n_pixels, int C, int act, float* db,
+                                int db_accumulate, void* stream) {
+  const int Cp = (C + 7) & ~7;
+  P2PHD_REQUIRE(Cp <= kMaxCp, "act_bwd_db: at most %d channels", kMaxCp);
+  P2PHD_REQUIRE(n_pixels >= 0 && C >= 1, "act_bwd_db: bad geometry");
+  P2PHD_REQUIRE(db != nullptr, "act_bwd_db: null bias-gradient pointer (use p2phd_act_bwd)");
+  hipStream_t st = (hipStream_t)stream;
+  if (!db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+  if (n_pixels == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(g && a && dx, "act_bwd_db: null pointer");
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  dim3 grid(stationary_grid(n_pixels, Cp / epp, 1));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(act_bwd_db_kernel<bf16_t>, grid, dim3(256), Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dx, (long)n_pixels, C, Cp, act, db),
+             hipLaunchKernelGGL(act_bwd_db_kernel<float>, grid, dim3(256), Cp * sizeof(float), st, (const float*)g, (const float*)a, (float*)dx, (long)n_pixels, C, Cp, act, db),
+             "act_bwd_db");
+  return p2phd::check_launch("act_bwd_db");
 }
