@@ -16,7 +16,8 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
     y = torch.empty(batch, Ho, Wo, _ops.cpitch(cout), device="cuda", dtype=torch.bfloat16)
     stats = torch.zeros(batch, _ops.cpitch(cout), 2, device="cuda")
     L = _ops.lib()
-    call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), None, _ops.stream_ptr()))
+    ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 16), dtype=torch.uint8, device="cuda")
+    call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
     flops = 2.0 * batch * Ho * Wo * cin * cout * k * k
     res = {0: [], 128: [], 256: [], 512: []}
     for r in range(rounds):
@@ -35,6 +36,11 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
         print(f"cin{cin} cout{cout} {H}x{W} k{k} B{batch}: BM={bm}: median {v[len(v)//2]:.1f} us  min {v[0]:.1f} us  -> {flops / v[len(v)//2] / 1e6:.0f} TFLOP/s")
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "thin":
+        run(cin=2, cout=48, H=512, W=256, k=7, pad=3, pad_mode=1, rounds=3, iters=5)
+        run(cin=48, cout=2, H=512, W=256, k=7, pad=3, pad_mode=1, rounds=3, iters=5)
+        run(cin=4, cout=64, H=512, W=256, k=4, pad=2, pad_mode=0, stride=2, rounds=3, iters=5)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "outer":
         run(cin=48, cout=96, H=512, W=256, k=3, pad=1, pad_mode=0, stride=2, rounds=3, iters=5)
         run(cin=96, cout=192, H=256, W=128, k=3, pad=1, pad_mode=0, stride=2, rounds=3, iters=5)
