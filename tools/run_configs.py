@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run one optimisation step of every BASELINE.json configuration that fits one GPU (robustness + timing)."""
+"""Run optimisation steps (graph replay) of every BASELINE.json configuration that fits one GPU (robustness + timing)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -28,18 +28,21 @@ def main():
         frames = opt.n_fft // 4
         T = (frames - 1) * opt.hop_length
         hr = 0.1 * torch.randn(B, T, device="cuda"); lr = 0.1 * torch.randn(B, T, device="cuda")
-        ld = model.train_step(lr, hr); torch.cuda.synchronize()
+        for _ in range(3):                                          # two eager steps + capture into HIP graphs
+            ld = model.train_step_graphed(lr, hr)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        n = 3
+        n = 5
         for _ in range(n):
-            ld = model.train_step(lr, hr)
+            ld = model.train_step_graphed(lr, hr)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         vals = {k: round(float(v), 4) for k, v in ld.items()}
         ok = all(torch.isfinite(p).all() for p in model.parameters())
         nG = sum(p.numel() for p in model.netG.parameters())
         print(f"{name}: {dt*1e3:.1f} ms/step, {B*frames/dt:.0f} frames/s, G params {nG}, finite={ok}, losses {vals}", flush=True)
-        del model
+        del model, ld
+        import gc; gc.collect()
         torch.cuda.empty_cache()
 
 if __name__ == "__main__":
