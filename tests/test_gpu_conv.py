@@ -181,3 +181,72 @@ def test_losses_and_adam():
         _lib.check(_lib.lib().p2phd_adam_step(_lib.ptr(p), _lib.ptr(gr.cuda()), _lib.ptr(m), _lib.ptr(v), n, 2e-4, 0.5, 0.999, 1e-8,
                                               step, 1.0, _lib.stream_ptr()))
     assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+
+
+def test_device_state_adam_and_accumulating_entry_points():
+    """The graph-capturable / in-place variants of the C ABI against their plain counterparts:
+    p2phd_adam_step_dev (learning rate + step counter in device memory) == torch.optim.Adam over steps with an LR change;
+    p2phd_conv_wgrad_acc, p2phd_instnorm_act_bwd_acc and p2phd_act_bwd_db add into (or fill) caller buffers."""
+    import ctypes as C
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    L = _lib.lib()
+    torch.manual_seed(5)
+    # --- Adam with device-side state
+    n = 1003
+    p0 = torch.randn(n)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.5, 0.999))
+    p = p0.clone().cuda()
+    m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    lr_dev = torch.tensor([2e-4], device="cuda"); step_dev = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for step in range(1, 6):
+        if step == 4:
+            opt.param_groups[0]["lr"] = 1e-4
+            lr_dev.fill_(1e-4)
+        gr = torch.randn(n)
+        ref.grad = gr.clone()
+        opt.step()
+        _lib.check(L.p2phd_adam_step_dev(_lib.ptr(p), _lib.ptr(gr.cuda()), _lib.ptr(m), _lib.ptr(v), n, _lib.ptr(lr_dev),
+                                         _lib.ptr(step_dev), 0.5, 0.999, 1e-8, 1.0, _lib.stream_ptr()))
+    assert int(step_dev.item()) == 5
+    assert float((p.cpu() - ref.detach()).abs().max()) < 1e-6
+    # --- wgrad_acc: twice into a zeroed buffer == 2 x the overwriting entry point; bias gradient likewise
+    spec = _ops.ConvSpec(24, 40, 3, 1, 1, 0, False, 0, False, _ops.ACT_NONE)
+    N, H, W = 2, 12, 10
+    x = torch.randn(N, H, W, _ops.cpitch(24), device="cuda"); x[..., 24:] = 0
+    d = spec.desc(N, H, W, torch.float32)
+    Ho, Wo = spec.out_size(d)
+    dy = torch.randn(N, Ho, Wo, _ops.cpitch(40), device="cuda"); dy[..., 40:] = 0
+    ws = torch.empty(max(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), 16), dtype=torch.uint8, device="cuda")
+    dw = torch.empty(40, 24, 3, 3, device="cuda"); db = torch.empty(40, device="cuda")
+    _lib.check(L.p2phd_conv_wgrad(C.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(dw), _lib.ptr(db), _lib.ptr(ws), _lib.stream_ptr()))
+    acc_w = torch.zeros_like(dw); acc_b = torch.zeros_like(db)
+    for _ in range(2):
+        _lib.check(L.p2phd_conv_wgrad_acc(C.byref(d), _lib.ptr(x), _lib.ptr(dy), _lib.ptr(acc_w), _lib.ptr(acc_b), _lib.ptr(ws),
+                                          _lib.stream_ptr()))
+    assert rel_err(acc_w.cpu().numpy(), 2 * dw.cpu().numpy()) < 1e-6 and rel_err(acc_b.cpu().numpy(), 2 * db.cpu().numpy()) < 1e-5
+    centre = torch.einsum("nhwk,nhwc->kc", dy[..., :40].cpu().double(), x[..., :24].cpu().double())      # tap (1,1): output pixel == input pixel
+    assert rel_err(dw[:, :, 1, 1].cpu().numpy(), centre.numpy()) < 1e-4
+    # --- act_bwd_db: dx and the column sums in one pass, fill and accumulate modes
+    a = torch.randn(N, Ho, Wo, _ops.cpitch(40), device="cuda"); g = torch.randn_like(a)
+    dx = torch.empty_like(a); dbb = torch.full((40,), 7.0, device="cuda")
+    _lib.check(L.p2phd_act_bwd_db(_lib.F32, _lib.ptr(g), _lib.ptr(a), _lib.ptr(dx), N * Ho * Wo, 40, _ops.ACT_LRELU, _lib.ptr(dbb), 0,
+                                  _lib.stream_ptr()))
+    want = g * torch.where(a > 0, torch.ones_like(a), torch.full_like(a, 0.2))
+    assert rel_err(dx.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    assert rel_err(dbb.cpu().numpy(), want[..., :40].sum((0, 1, 2)).cpu().numpy()) < 1e-5
+    _lib.check(L.p2phd_act_bwd_db(_lib.F32, _lib.ptr(g), _lib.ptr(a), _lib.ptr(dx), N * Ho * Wo, 40, _ops.ACT_LRELU, _lib.ptr(dbb), 1,
+                                  _lib.stream_ptr()))
+    assert rel_err(dbb.cpu().numpy(), 2 * want[..., :40].sum((0, 1, 2)).cpu().numpy()) < 1e-5
+    # --- instnorm_act_bwd_acc: same dy as the overwriting entry point, db added on top of what was there
+    y = torch.randn(N, Ho, Wo, _ops.cpitch(40), device="cuda"); y[..., 40:] = 0
+    stats = torch.stack([y.sum((1, 2)), (y * y).sum((1, 2))], dim=-1).contiguous()
+    bst = torch.empty(N, _ops.cpitch(40), 2, device="cuda")
+    dy1 = torch.empty_like(y); dy2 = torch.empty_like(y)
+    db1 = torch.empty(40, device="cuda"); db2 = torch.full((40,), 3.0, device="cuda")
+    _lib.check(L.p2phd_instnorm_act_bwd(_lib.F32, _lib.ptr(g), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(bst), _lib.ptr(dy1), _lib.ptr(db1), N,
+                                        Ho * Wo, 40, 1e-5, _ops.ACT_RELU, _lib.stream_ptr()))
+    _lib.check(L.p2phd_instnorm_act_bwd_acc(_lib.F32, _lib.ptr(g), _lib.ptr(y), _lib.ptr(stats), _lib.ptr(bst), _lib.ptr(dy2), _lib.ptr(db2), N,
+                                            Ho * Wo, 40, 1e-5, _ops.ACT_RELU, _lib.stream_ptr()))
+    assert rel_err(dy2.cpu().numpy(), dy1.cpu().numpy()) < 1e-5      # the per-(n,c) sums are float atomics: not bit-identical run to run
+    assert float((db2 - 3.0 - db1).abs().max()) < 1e-3
