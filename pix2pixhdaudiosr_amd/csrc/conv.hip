@@ -541,6 +541,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     g_dh[j] = d.dh0 + ta * d.dh_step; g_dw[j] = d.dw0 + tb * d.dw_step;
     g_cB[j] = (unsigned)((kk - t * Cpi) * SZ);
   }
+  unsigned g_offB[PPT];                                       // (dh * Win + dw) * bytes per pixel + channel offset, mod 2^32
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) g_offB[j] = (unsigned)(g_dh[j] * Win + g_dw[j]) * (unsigned)(Cpi * SZ) + g_cB[j];
   const bool same_tap = g_ok[0] && g_ok[PPT - 1] && g_dh[0] == g_dh[PPT - 1] && g_dw[0] == g_dw[PPT - 1] &&
                         (j0 + (grp * PPT) * CPP + chunk * EPP) / Cpi == (j0 + (grp * PPT + PPT - 1) * CPP + chunk * EPP) / Cpi;
   // rows-operand pieces
@@ -573,19 +576,44 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     pn = (int)nn; ph = rem / Wg; pw = rem - ph * Wg;
   }
   long pA = (long)s_begin * BKP + rowA;
+  unsigned aB = (unsigned)pA * CprB;                          // byte offset of this thread's rows-operand pixel, advanced per step
   unsigned vG[PPT], vA[PPTA];
-
+  // one K step moves the pixel by BKP: as (samples, rows, columns) so the walk is three adds with carries, no loops
+  const int adv_n = BKP / npix, adv_rem = BKP - adv_n * npix;
+  const int adv_h = adv_rem / Wg, adv_w = adv_rem - adv_h * Wg;
+  const bool reflect = pad_mode == 1;
+  // 24-bit multiplies are full rate (v_mad_u32_u24); the host guarantees N * Hin * Win < 2^31 and Hin, Win < 2^24
   auto pix_off = [&](int dh, int dw) -> unsigned {
-    int hi = ph * sh + dh, wi = pw * sw + dw;
-    if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
-    return ((unsigned)hi < (unsigned)Hin && (unsigned)wi < (unsigned)Win) ? (unsigned)((pn * Hin + hi) * Win + wi) * CpiB : kOOB;
+    int hi = __mul24(ph, sh) + dh, wi = __mul24(pw, sw) + dw;
+    if (reflect) {                                              // branch-free |.| and mirror at the far edge
+      hi = hi < 0 ? -hi : hi; hi = hi >= Hin ? 2 * (Hin - 1) - hi : hi;
+      wi = wi < 0 ? -wi : wi; wi = wi >= Win ? 2 * (Win - 1) - wi : wi;
+    }
+    const bool ok = (unsigned)hi < (unsigned)Hin && (unsigned)wi < (unsigned)Win;
+    const unsigned pix = (unsigned)(__mul24(pn, Hin) + hi) * (unsigned)Win + (unsigned)wi;
+    return ok ? pix * CpiB : kOOB;
   };
+#ifdef P2PHD_ABL_WGRAD_NOPREP
+  int abl_prep = 0;
+#endif
   auto prepare = [&]() {
+#ifdef P2PHD_ABL_WGRAD_NOPREP
+    if (abl_prep++ >= 3) return;                                 // timing experiment only: stale gather offsets afterwards
+#endif
     if (pcur < P) {
       if (same_tap) {
         const unsigned o = pix_off(g_dh[0], g_dw[0]);
 #pragma unroll
         for (int j = 0; j < PPT; ++j) vG[j] = o == kOOB ? kOOB : o + g_cB[j];
+      } else if (!reflect) {
+        // zero padding: every tap is the un-shifted pixel plus a per-piece constant; only the bounds test is per tap
+        const int hb = __mul24(ph, sh), wb = __mul24(pw, sw);
+        const unsigned baseB = ((unsigned)(__mul24(pn, Hin) + hb) * (unsigned)Win + (unsigned)wb) * CpiB;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+          const bool ok = g_ok[j] && (unsigned)(hb + g_dh[j]) < (unsigned)Hin && (unsigned)(wb + g_dw[j]) < (unsigned)Win;
+          vG[j] = ok ? baseB + g_offB[j] : kOOB;
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
@@ -598,11 +626,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       for (int j = 0; j < PPT; ++j) vG[j] = kOOB;
     }
 #pragma unroll
-    for (int j = 0; j < PPTA; ++j) vA[j] = (a_ok[j] && pA < P) ? (unsigned)pA * CprB + a_cB[j] : kOOB;
-    pcur += BKP; pA += BKP;
-    pw += BKP;
-    while (pw >= Wg) { pw -= Wg; ++ph; }
-    while (ph >= Hg) { ph -= Hg; ++pn; }
+    for (int j = 0; j < PPTA; ++j) vA[j] = (a_ok[j] && pA < P) ? aB + a_cB[j] : kOOB;
+    pcur += BKP; pA += BKP; aB += (unsigned)BKP * CprB;
+    pw += adv_w;
+    const int cw = pw >= Wg ? 1 : 0;
+    pw -= cw ? Wg : 0;
+    ph += adv_h + cw;
+    const int ch = ph >= Hg ? 1 : 0;
+    ph -= ch ? Hg : 0;
+    pn += adv_n + ch;
   };
   // piece j of a tile: 0..3 gather panels, 4.. rows-operand panels
   auto issue_piece = [&](int slot_, int j) {
