@@ -27,50 +27,59 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 }
 
 // Xe[n,h,wo,(tw*C + c)] = x[n,h,map(wo + tw - pad),c]   (map = reflect or zero), wo in [0,Wo)
-// one thread per output pixel: gathers its S*C values and writes the Cep-channel row as 16-byte pieces
+// One thread per 16-byte output piece; its elements are gathered into registers with compile-time indices (a per-pixel
+// row[] array filled at run-time positions lives in scratch memory and made this kernel 3-4x slower than its traffic).
 template <typename T>
 __global__ __launch_bounds__(256) void expand_in_kernel(const T* __restrict__ x, T* __restrict__ xe, long NH, int W, int Wo, int C, int Cp,
                                                         int S, int pad, int pad_mode, int Cep) {
-  const long total = NH * Wo;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  const int ppr = Cep / EPP;
+  const long total = NH * Wo * ppr;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int wo = (int)(e % Wo);
-    const long nh = e / Wo;
-    alignas(16) T row[32];
+    const int pc = (int)(e % ppr);
+    const long pix = e / ppr;
+    const int wo = (int)(pix % Wo);
+    const long nh = pix / Wo;
+    const T* srow = x + nh * W * Cp;
+    alignas(16) T vals[EPP];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) row[i] = from_f<T>(0.f);
-    for (int tw = 0; tw < S; ++tw) {
+    for (int j = 0; j < EPP; ++j) {
+      const int q = pc * EPP + j;
+      const int tw = q / C, c = q - tw * C;
       int wi = wo + tw - pad;
       if (pad_mode == 1) wi = reflect_idx(wi, W);
-      if (wi < 0 || wi >= W) continue;
-      const T* src = x + (nh * W + wi) * Cp;
-      for (int c = 0; c < C; ++c) row[tw * C + c] = src[c];
+      const bool ok = tw < S && wi >= 0 && wi < W;
+      const T v = srow[(size_t)(ok ? wi : 0) * Cp + c];          // unconditional load, masked below
+      vals[j] = ok ? v : from_f<T>(0.f);
     }
-    uint4* dst = reinterpret_cast<uint4*>(xe + e * Cep);
-    const uint4* r4 = reinterpret_cast<const uint4*>(row);
-    for (int i = 0; i < Cep * (int)sizeof(T) / 16; ++i) dst[i] = r4[i];
+    *reinterpret_cast<uint4*>(xe + e * EPP) = *reinterpret_cast<const uint4*>(vals);
   }
 }
 
-// dyE[n,h,w',(tw*K + k)] = dy[n,h,w'-tw,k] (zero outside [0,Wo)), w' in [0,Wy); one thread per folded pixel
+// dyE[n,h,w',(tw*K + k)] = dy[n,h,w'-tw,k] (zero outside [0,Wo)), w' in [0,Wy); one thread per 16-byte output piece
 template <typename T>
 __global__ __launch_bounds__(256) void expand_dy_kernel(const T* __restrict__ dy, T* __restrict__ dye, long NH, int Wo, int Wy, int K, int Kp,
                                                         int S, int Cep) {
-  const long total = NH * Wy;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  const int ppr = Cep / EPP;
+  const long total = NH * Wy * ppr;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int wy = (int)(e % Wy);
-    const long nh = e / Wy;
-    alignas(16) T row[32];
+    const int pc = (int)(e % ppr);
+    const long pix = e / ppr;
+    const int wy = (int)(pix % Wy);
+    const long nh = pix / Wy;
+    const T* srow = dy + nh * Wo * Kp;
+    alignas(16) T vals[EPP];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) row[i] = from_f<T>(0.f);
-    for (int tw = 0; tw < S; ++tw) {
+    for (int j = 0; j < EPP; ++j) {
+      const int q = pc * EPP + j;
+      const int tw = q / K, k = q - tw * K;
       const int w = wy - tw;
-      if (w < 0 || w >= Wo) continue;
-      const T* src = dy + (nh * Wo + w) * Kp;
-      for (int k = 0; k < K; ++k) row[tw * K + k] = src[k];
+      const bool ok = tw < S && w >= 0 && w < Wo;
+      const T v = srow[(size_t)(ok ? w : 0) * Kp + k];
+      vals[j] = ok ? v : from_f<T>(0.f);
     }
-    uint4* dst = reinterpret_cast<uint4*>(dye + e * Cep);
-    const uint4* r4 = reinterpret_cast<const uint4*>(row);
-    for (int i = 0; i < Cep * (int)sizeof(T) / 16; ++i) dst[i] = r4[i];
+    *reinterpret_cast<uint4*>(dye + e * EPP) = *reinterpret_cast<const uint4*>(vals);
   }
 }
 
@@ -90,14 +99,17 @@ __global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, cons
     alignas(16) T outv[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) outv[k] = from_f<T>(0.f);
-    for (int k = 0; k < K; ++k) {
-      float a = bias != nullptr ? bias[k] : 0.f;
-      for (int tw = 0; tw < S; ++tw) a += to_f(row[(size_t)tw * Cep + tw * K + k]);
-      s1[k] += a; s2[k] += a * a;
-      if (act == P2PHD_ACT_TANH) a = tanhf(a);
-      else if (act == P2PHD_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
-      else if (act == P2PHD_ACT_RELU) a = a > 0.f ? a : 0.f;
-      outv[k] = from_f<T>(a);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                                // K <= 4; literal k keeps s1 / s2 / outv in registers
+      if (k < K) {
+        float a = bias != nullptr ? bias[k] : 0.f;
+        for (int tw = 0; tw < S; ++tw) a += to_f(row[(size_t)tw * Cep + tw * K + k]);
+        s1[k] += a; s2[k] += a * a;
+        if (act == P2PHD_ACT_TANH) a = tanhf(a);
+        else if (act == P2PHD_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
+        else if (act == P2PHD_ACT_RELU) a = a > 0.f ? a : 0.f;
+        outv[k] = from_f<T>(a);
+      }
     }
     T* o = y + ((size_t)n * HW + p) * Kp;
     if (sizeof(T) == 2) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(outv);
@@ -105,7 +117,8 @@ __global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, cons
   }
   if (stats != nullptr) {
     __shared__ float red[4][8];
-    for (int k = 0; k < K; ++k) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
       float a = s1[k], b = s2[k];
       for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
       if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * k] = a; red[threadIdx.x >> 6][2 * k + 1] = b; }
@@ -128,8 +141,8 @@ int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, in
                      hipStream_t st) {
   const int Cp = cpitch(C), Cep = cpitch(S * C);
   const long NH = (long)N * H;
-  const long total = NH * Wo;
-  P2PHD_REQUIRE(Cep <= 32, "expand_in: folded channel count must be <= 32");
+  const long total = NH * Wo * (Cep / (dtype == P2PHD_BF16 ? 8 : 4));
+  P2PHD_REQUIRE(Cep <= 32 && C >= 1, "expand_in: folded channel count must be <= 32");
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(expand_in_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)xe, NH, W, Wo, C, Cp, S, pad, pad_mode, Cep);
   else
@@ -140,8 +153,8 @@ int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, in
 int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st) {
   const int Kp = cpitch(K), Cep = cpitch(S * K);
   const long NH = (long)N * Ho;
-  const long total = NH * Wy;
-  P2PHD_REQUIRE(Cep <= 32, "expand_dy: folded channel count must be <= 32");
+  const long total = NH * Wy * (Cep / (dtype == P2PHD_BF16 ? 8 : 4));
+  P2PHD_REQUIRE(Cep <= 32 && K >= 1, "expand_dy: folded channel count must be <= 32");
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(expand_dy_kernel<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dye, NH, Wo, Wy, K, Kp, S, Cep);
   else
