@@ -1,0 +1,46 @@
+"""Two data-parallel ranks of the product step on ONE GPU (gloo between them): the flat-buffer gradient exchange inside
+`train_step` and between the replays of `train_step_graphed`.  Replicas must end bit-identical; the
+data-parallel result must equal a single process on the concatenated batch up to fp32 / bf16 rounding noise."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(mode, out_dir):
+    port = 29600 + (os.getpid() + (7 if mode == "graphed" else 0)) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_dp_gpu_worker.py"), str(out_dir), mode]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("mode", ["eager", "graphed"])
+def test_two_ranks_one_gpu(tmp_path, mode):
+    _run(mode, tmp_path)
+    r0 = torch.load(tmp_path / f"{mode}_rank0.pt")
+    r1 = torch.load(tmp_path / f"{mode}_rank1.pt")
+    assert r0["steps"] == r1["steps"] == 5
+    assert r0["graphed"] == (mode == "graphed")
+    assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["D"], r1["D"])      # replicas stay bit-identical
+    assert torch.isfinite(r0["G"]).all() and torch.isfinite(r0["D"]).all()
+    for step_losses in r0["losses"]:
+        assert all(abs(v) < 1e3 for v in step_losses.values())
+    if mode == "eager":
+        s = torch.load(tmp_path / "single.pt")
+        # losses of the first step: mean over the full batch == mean of the two shard means
+        r1l = r1["losses"][0]
+        for k, v in s["losses"].items():
+            dp = 0.5 * (r0["losses"][0][k] + r1l[k])
+            assert abs(dp - v) <= 1e-4 * max(1.0, abs(v)), (k, dp, v)
+        # weights after ONE update: the first Adam step moves every element by lr * sign(grad), so DP and single process
+        # differ (by 2 lr) only where rounding flipped the sign of a near-zero gradient
+        for k in ("G", "D"):
+            d = (r0["first"][k] - s[k]).abs()
+            assert float(d.max()) <= 4.5e-4, (k, float(d.max()))
+            assert float((d > 1e-5).float().mean()) < 0.05, (k, float((d > 1e-5).float().mean()))
