@@ -142,25 +142,24 @@ class AudioDataset(BaseDataset):
         return out
 
     def get_files(self, file_path):
+        """Directory -> every .wav below it; otherwise a csv whose cells are paths relative to the csv's folder
+        (audio_dataset.py:64-79; the reference's extension test accepts anything, this build decodes RIFF/WAVE only)."""
         if os.path.isdir(file_path):
+            found = [os.path.join(folder, name) for folder, _, names in os.walk(file_path, topdown=False)
+                     for name in names if name.lower().endswith(".wav")]
             print("Searching for audio file")
-            file_list = []
-            for root, _, files in os.walk(file_path, topdown=False):
-                for name in files:
-                    if os.path.splitext(name)[1].lower() == ".wav":   # this build decodes RIFF/WAVE only
-                        file_list.append(os.path.join(root, name))
         else:
+            base = os.path.dirname(file_path)
+            with open(file_path, newline="") as fh:
+                found = [os.path.join(base, cell) for line in csv.reader(fh) for cell in line]
             print("Using csv file list")
-            root, _ = os.path.split(file_path)
-            with open(file_path, 'r') as csv_file:
-                file_list = [os.path.join(root, item) for sub in csv.reader(csv_file) for item in sub]
-        print(len(file_list))
-        return file_list
+        print(len(found))
+        return found
 
     def seg_pad_audio(self, waveform):
-        if waveform.size(1) >= self.segment_length:
-            return waveform[0][:self.segment_length]
-        return F.pad(waveform, (0, self.segment_length - waveform.size(1)), 'constant')
+        """[C, T] -> first channel cropped to segment_length (1-D), or the [C, segment_length] right-padded tensor."""
+        missing = self.segment_length - waveform.size(1)
+        return waveform[0][:self.segment_length] if missing <= 0 else F.pad(waveform, (0, missing))
 
 
 class AudioTestDataset(BaseDataset):
@@ -200,10 +199,8 @@ class AudioTestDataset(BaseDataset):
                 'feat': torch.empty(1), 'path': self.dataroot}
 
     def seg_pad_audio(self, audio):
+        """[1, T] or [T] -> [ceil(T / segment_length), segment_length], zero padded at the end."""
         audio = audio.squeeze(0)
-        length = len(audio)
-        if length >= self.segment_length:
-            num_segments = int(math.ceil(length / self.segment_length))
-            audio = F.pad(audio, (0, self.segment_length * num_segments - length), "constant")
-            return audio.unfold(dimension=0, size=self.segment_length, step=self.segment_length)
-        return F.pad(audio, (0, self.segment_length - length), 'constant').unsqueeze(0)
+        segments = max(1, int(math.ceil(len(audio) / self.segment_length)))
+        audio = F.pad(audio, (0, segments * self.segment_length - len(audio)))
+        return audio.view(segments, self.segment_length)

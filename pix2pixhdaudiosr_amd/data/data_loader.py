@@ -35,42 +35,49 @@ class _FedLoader:
 
 
 class CustomDatasetDataLoader:
+    """Train: shuffled train / validation split (indices saved next to the checkpoints) behind worker processes that
+    only read PCM, then the GPU feeder stage; test: the segments already live on the GPU."""
+
     def name(self):
         return 'CustomDatasetDataLoader'
+
+    def _loader(self, indices, feeder):
+        opt = self.opt
+        return _FedLoader(torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, sampler=SubsetRandomSampler(indices),
+                                                      num_workers=int(opt.nThreads), pin_memory=True), feeder)
+
+    def _split(self, n):
+        opt = self.opt
+        given = getattr(opt, 'val_indices', None)
+        if given is not None:
+            val = [int(i) for i in torch.load(given)]
+            held = set(val)
+            return [i for i in range(n) if i not in held], val
+        order = list(range(n))
+        if not opt.serial_batches:
+            random.Random(opt.seed).shuffle(order)
+        cut = int(opt.validation_split * n)
+        folder = os.path.join(opt.checkpoints_dir, opt.name)
+        os.makedirs(folder, exist_ok=True)
+        torch.save(order[:cut], os.path.join(folder, 'validation_indices.pt'))
+        return order[cut:], order[:cut]
 
     def initialize(self, opt):
         self.opt = opt
         self.dataset = CreateDataset(opt)
-        dataset_size = len(self.dataset)
-        indices = list(range(dataset_size))
+        n = len(self.dataset)
         if opt.phase == "train":
-            split = int(opt.validation_split * dataset_size)
-            if getattr(opt, 'val_indices', None) is not None:
-                self.val_indices = torch.load(opt.val_indices)
-                self.train_indices = sorted(set(indices) - set(int(i) for i in self.val_indices))
-            else:
-                if not opt.serial_batches:
-                    random.seed(opt.seed)
-                    random.shuffle(indices)
-                self.train_indices, self.val_indices = indices[split:], indices[:split]
-                out_dir = os.path.join(opt.checkpoints_dir, opt.name)
-                os.makedirs(out_dir, exist_ok=True)
-                torch.save(self.val_indices, os.path.join(out_dir, 'validation_indices.pt'))
-            self.data_lenth = min(len(self.train_indices), opt.max_dataset_size)
+            self.train_indices, self.val_indices = self._split(n)
             feeder = GpuFeeder(opt)
-            mk = lambda idx: _FedLoader(torch.utils.data.DataLoader(
-                self.dataset, batch_size=opt.batchSize, sampler=SubsetRandomSampler(idx), num_workers=int(opt.nThreads),
-                pin_memory=True), feeder)
-            self.dataloader = mk(self.train_indices)
-            self.eval_dataloder = mk(self.val_indices) if len(self.val_indices) != 0 else None
+            self.dataloader = self._loader(self.train_indices, feeder)
+            self.eval_dataloder = self._loader(self.val_indices, feeder) if self.val_indices else None
+            self.data_lenth = min(len(self.train_indices), opt.max_dataset_size)
             self.eval_data_lenth = len(self.val_indices)
         else:
-            self.data_lenth = min(dataset_size, opt.max_dataset_size)
-            # the segments already live on the GPU: no workers, no pinning
             self.dataloader = _FedLoader(torch.utils.data.DataLoader(self.dataset, batch_size=opt.batchSize, num_workers=0,
                                                                      shuffle=False), None)
-            self.eval_dataloder = None
-            self.eval_data_lenth = 0
+            self.eval_dataloder, self.eval_data_lenth = None, 0
+            self.data_lenth = min(n, opt.max_dataset_size)
 
     def load_data(self):
         return self.dataloader

@@ -12,36 +12,11 @@ class BaseModel(torch.nn.Module):
         return 'BaseModel'
 
     def initialize(self, opt):
-        self.opt = opt
-        self.gpu_ids = opt.gpu_ids
-        self.isTrain = opt.isTrain
-        self.Tensor = torch.cuda.FloatTensor if self.gpu_ids else torch.Tensor
+        self.opt, self.isTrain, self.gpu_ids = opt, opt.isTrain, list(opt.gpu_ids)
         self.save_dir = os.path.join(opt.checkpoints_dir, opt.name)
-        self.device = 'cuda' if len(self.gpu_ids) > 0 else 'cpu'
-
-    def set_input(self, input):
-        self.input = input
-
-    def forward(self):
-        pass
-
-    def test(self):
-        pass
-
-    def get_image_paths(self):
-        pass
-
-    def optimize_parameters(self):
-        pass
-
-    def get_current_visuals(self):
-        return self.input
-
-    def get_current_errors(self):
-        return {}
-
-    def save(self, label):
-        pass
+        # the reference falls back to the CPU without gpu_ids; this build has no CPU path and says so at first use
+        self.device = torch.device('cuda', self.gpu_ids[0]) if self.gpu_ids else torch.device('cpu')
+        self.Tensor = torch.cuda.FloatTensor if self.gpu_ids else torch.Tensor
 
     def save_network(self, network, network_label, epoch_label, gpu_ids):
         """fp32 CPU state_dict under the reference's file name; the network itself stays on the GPU."""
@@ -79,6 +54,3 @@ class BaseModel(torch.nn.Module):
                 print(missing)
                 network.load_state_dict(merged)
         _ops.bump_weight_epoch()
-
-    def update_learning_rate(self):
-        pass
