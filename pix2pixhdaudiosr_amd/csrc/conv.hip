@@ -941,26 +941,30 @@ __global__ __launch_bounds__(256) void pack_dense_kernel(GDesc d, p2phd::WMap m,
   }
 }
 
+// TT = compile-time tap count (9: 3x3, 16: 4x4) so that exactly TT loads per slab are issued; 0 = any count <= 16
+// (loads clamped to the last tap: up to 16 issued)
+template <int TT>
 __global__ __launch_bounds__(256) void unpack_dense_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ dwp,
                                                            float* __restrict__ dw, int splits, long slab_elems, int accumulate) {
   __shared__ float tile[4][64 * 16];
-  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in;
+  const int T_taps = TT > 0 ? TT : d.nth * d.ntw, Cp = d.Cp_in;
+  constexpr int NV = TT > 0 ? TT : 16;
   const int tx = threadIdx.x, ty = threadIdx.y;
   const int row = blockIdx.y * 4 + ty, c0 = blockIdx.x * 64;
   const bool row_ok = row < m.rows;
   const int ncols = max(0, min(64, m.inner - c0));
   if (row_ok && tx < ncols) {
-    float v[16];
+    float v[NV];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = 0.f;
+    for (int i = 0; i < NV; ++i) v[i] = 0.f;
     const float* srow = dwp + (size_t)row * d.KK + c0 + tx;
     for (int z = 0; z < splits; ++z) {                           // fixed order: reproducible
       const float* src = srow + (size_t)z * slab_elems;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] += src[(size_t)min(i, T_taps - 1) * Cp];
+      for (int i = 0; i < NV; ++i) v[i] += src[(size_t)min(i, T_taps - 1) * Cp];
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i)
+    for (int i = 0; i < NV; ++i)
       if (i < T_taps) tile[ty][tx * T_taps + i] = v[i];
   }
   __syncthreads();
@@ -968,6 +972,78 @@ __global__ __launch_bounds__(256) void unpack_dense_kernel(GDesc d, p2phd::WMap 
     float* dst = dw + (long)row * m.s_row + (long)c0 * T_taps;
     for (int i = tx; i < ncols * T_taps; i += 64) dst[i] = accumulate ? dst[i] + tile[ty][i] : tile[ty][i];
   }
+}
+
+// Transposing variant for master tensors laid out [inner][rows][R*S] (the input-gradient pack of a Conv2d: packed rows =
+// input channels, packed inner = output channels): a block moves a 64 (inner) x 16 (rows) x R*S brick through LDS, so
+// both the master reads (R*S * 16 contiguous floats per inner index) and the packed writes (64 consecutive inner
+// indices) are coalesced; the generic kernel reads this case with one cache line per lane.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_transposed_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp,
+                                                              int rows_pad) {
+  constexpr int RB = 16;
+  __shared__ float tile[64][RB * 16 + 1];
+  __shared__ int tapidx[16];
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK, RS = (int)m.s_row;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int k0 = blockIdx.x * 64, row0 = blockIdx.y * RB;
+  if (ty == 0 && tx < T_taps) {
+    const int ta = tx / d.ntw, tb = tx - ta * d.ntw;
+    tapidx[tx] = (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+  }
+  const int nrows = max(0, min(RB, m.rows - row0));
+  // 4 x 4 unconditional (clamped) loads in flight per thread and pass: a load inside a data-dependent branch is
+  // serialised by its own s_waitcnt
+  const int run = nrows * RS;                                    // contiguous floats per inner index (<= 256)
+#pragma unroll
+  for (int kb = 0; kb < (run > 0 ? 64 : 0); kb += 16) {          // run == 0: a block of padding rows reads nothing
+    float v[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = kb + 4 * kk + ty;
+      const float* src = w + (long)min(k0 + k, m.inner - 1) * m.s_inner + (long)row0 * RS;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[kk][q] = src[min(tx + 64 * q, max(run - 1, 0))];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = kb + 4 * kk + ty;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (tx + 64 * q < run) tile[k][tx + 64 * q] = v[kk][q];
+    }
+  }
+  __syncthreads();
+  const bool k_ok = k0 + tx < m.inner;
+  if (k0 + tx < Cp) {
+    for (int r = ty; r < RB; r += 4) {
+      const int row = row0 + r;
+      if (row >= rows_pad) break;
+      T* orow = wp + (size_t)row * KK + k0 + tx;
+      const bool ok = k_ok && r < nrows;
+      for (int t = 0; t < T_taps; ++t) orow[(size_t)t * Cp] = from_f<T>(ok ? tile[tx][r * RS + tapidx[t]] : 0.f);
+    }
+  }
+  if (blockIdx.x == 0) {                                          // zero tail of the padded K extent
+    for (int r = ty; r < RB; r += 4) {
+      const int row = row0 + r;
+      if (row >= rows_pad) break;
+      for (int kk = T_taps * Cp + tx; kk < KK; kk += 64) wp[(size_t)row * KK + kk] = from_f<T>(0.f);
+    }
+  }
+}
+
+inline bool transposed_map(const GDesc& d, const p2phd::WMap& m) {
+  const int T_taps = d.nth * d.ntw;
+  if (!(T_taps <= 16 && m.s_row >= 1 && m.s_row <= 16 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.inner > 0 && m.rows > 0 &&
+        m.s_inner >= (long)m.rows * m.s_row))
+    return false;
+  for (int t = 0; t < T_taps; ++t) {                             // every tap must address inside the R*S block
+    const int ta = t / d.ntw, tb = t - ta * d.ntw;
+    const int idx = (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+    if (idx < 0 || idx >= m.s_row) return false;
+  }
+  return true;
 }
 
 inline bool dense_map(const GDesc& d, const p2phd::WMap& m) {
@@ -1294,7 +1370,10 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
   if (m.rows > 0 && m.inner > 0) {
     if (dense_map(d, m)) {
       const dim3 grid((unsigned)((m.inner + 63) / 64), (unsigned)((m.rows + 3) / 4));
-      hipLaunchKernelGGL(unpack_dense_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+      const int tt = d.nth * d.ntw;
+      if (tt == 9) hipLaunchKernelGGL(unpack_dense_kernel<9>, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+      else if (tt == 16) hipLaunchKernelGGL(unpack_dense_kernel<16>, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
+      else hipLaunchKernelGGL(unpack_dense_kernel<0>, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
     } else {
       const dim3 grid((unsigned)std::min((m.inner + 63) / 64, 64), (unsigned)((m.rows + 3) / 4));
       hipLaunchKernelGGL(unpack_grad_kernel, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
@@ -1323,6 +1402,14 @@ int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* 
     else
       hipLaunchKernelGGL(pack_dense_kernel<float>, dgrid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
     return check_launch("pack_weights(dense)");
+  }
+  if (transposed_map(d, m)) {
+    const dim3 tgrid((unsigned)((d.Cp_in + 63) / 64), (unsigned)((rows_pad + 15) / 16));
+    if (dtype == P2PHD_BF16)
+      hipLaunchKernelGGL(pack_transposed_kernel<bf16_t>, tgrid, dim3(64, 4), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
+    else
+      hipLaunchKernelGGL(pack_transposed_kernel<float>, tgrid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
+    return check_launch("pack_weights(transposed)");
   }
   const dim3 grid((unsigned)std::min((d.Cp_in + 63) / 64, 64), (unsigned)((rows_pad + 3) / 4));
   if (dtype == P2PHD_BF16)
