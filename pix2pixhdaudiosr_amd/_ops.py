@@ -50,6 +50,7 @@ def begin_step(device, nbytes=32 << 20):
         _ARENA[device] = a
     a["buf"].zero_()
     a["off"], a["live"] = 0, True
+    a["gen"] = a.get("gen", 0) + 1
 
 
 def end_arena(device):
@@ -71,6 +72,22 @@ def zeros(shape, device):
     t = a["buf"][a["off"]:a["off"] + n * 4].view(torch.float32).view(shape)
     a["off"] += nbytes
     return t
+
+
+def arena_generation(device):
+    """Generation of the device's step arena (0 when there is none): a slice taken in generation g is recycled by the
+    next begin_step(), so a backward that still needs it must run before that."""
+    a = _ARENA.get(str(device))
+    return a["gen"] if a is not None and a["live"] else 0
+
+
+def _check_arena(ctx, device):
+    g = getattr(ctx, "arena_gen", 0)
+    if g:
+        a = _ARENA.get(str(device))
+        if a is None or a.get("gen", 0) != g:
+            raise _lib.P2PHDError("the InstanceNorm statistics of this forward pass were recycled: a new training-step forward "
+                                  "started before this backward ran (run backward before the next forward)")
 
 
 # measurement hook: `match(spec, N, H, W) -> bool` selects conv layers whose forward launch is bracketed by HIP events on
@@ -290,6 +307,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.has_res = residual is not None
         ctx.x, ctx.y, ctx.stats, ctx.weight, ctx.bias = x, y, stats, weight, bias
         ctx.link = link
+        ctx.arena_gen = arena_generation(x.device) if spec.norm else 0
         return out
 
     @staticmethod
@@ -297,6 +315,7 @@ class ConvBlockFn(torch.autograd.Function):
         spec, d = ctx.spec, ctx.d
         L = lib()
         x, y, stats, weight = ctx.x, ctx.y, ctx.stats, ctx.weight
+        _check_arena(ctx, y.device)
         g = g.contiguous()
         if g.dtype != y.dtype:
             g = g.to(y.dtype)

@@ -227,3 +227,17 @@ def test_graphed_step_equals_eager_step(golden_model):
                 continue                                           # biases behind InstanceNorm: pure-noise gradients
             da = (pa - pb).abs().max().item()
             assert da <= 2.5e-3, (ka, da)                          # <= 2 lr per update on noise-dominated elements, 5 updates
+
+
+def test_stale_forward_is_refused(golden_model):
+    """The per-step arena that holds the InstanceNorm statistics is recycled by the next step's forward: a backward that
+    still needs the old statistics must fail loudly instead of using zeroed sums."""
+    from pix2pixhdaudiosr_amd import _lib
+    g = golden_model
+    lr, hr = torch.from_numpy(g["lr"]).cuda(), torch.from_numpy(g["hr"]).cuda()
+    m = _model(g, mask=False)
+    losses1, _ = m.forward(lr, None, hr, None)
+    m.forward(lr, None, hr, None)                                  # a second forward recycles the arena
+    ld = dict(zip(m.loss_names, losses1))
+    with pytest.raises(_lib.P2PHDError):
+        (ld['G_GAN'] + ld['G_GAN_Feat']).backward()
