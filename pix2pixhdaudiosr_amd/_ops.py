@@ -110,6 +110,21 @@ def backward_without_weight_grads(params):
         _BWD_SKIP_WGRAD_IDS.difference_update(ids)
 
 
+# conv layers whose INPUT gradient is not wanted by the backward pass running right now (the first layer of each
+# discriminator scale during the D-loss pass: its input is the generator output, which that pass must not touch)
+_BWD_SKIP_DGRAD_SPECS = set()
+
+
+@contextlib.contextmanager
+def backward_without_input_grads(specs):
+    ids = {id(sp) for sp in specs}
+    _BWD_SKIP_DGRAD_SPECS.update(ids)
+    try:
+        yield
+    finally:
+        _BWD_SKIP_DGRAD_SPECS.difference_update(ids)
+
+
 def _direct_grad(p):
     """True when `p.grad` is FlatAdam's view of its flat gradient buffer (optim.py marks the parameter)."""
     g = p.grad
@@ -355,7 +370,7 @@ class ConvBlockFn(torch.autograd.Function):
             check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
             if direct:
                 gw = gb = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and id(spec) not in _BWD_SKIP_DGRAD_SPECS:
             wp = spec.packed(weight, 1, d)
             gx = torch.empty_like(x)
             wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))

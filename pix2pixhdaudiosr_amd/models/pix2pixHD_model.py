@@ -313,7 +313,9 @@ class Pix2PixHDModel(BaseModel):
     def _phase_b(self):
         """Backward of the discriminator loss through the graph phase A kept."""
         loss_D, self._loss_D = self._loss_D, None
-        loss_D.backward(inputs=list(self.optimizer_D._params))
+        firsts = [self.netD._scale_steps(d)[0][0].spec for d in range(self.opt.num_D)]
+        with _ops.backward_without_input_grads(firsts):            # no gradient towards the generator in this pass
+            loss_D.backward(inputs=list(self.optimizer_D._params))
 
     def train_step(self, lr_audio, hr_audio, noise=None):
         ld = self._phase_a(lr_audio, hr_audio, noise)
