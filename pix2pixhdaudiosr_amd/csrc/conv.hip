@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   // descriptor fields used in loops live in registers (a by-value struct that is captured by reference ends
   // up in scratch memory)
   const int Cp = d.Cp_in, KK = d.KK, Wg = d.Wg, T_taps = d.nth * d.ntw, npix = d.Hg * d.Wg;
-  const int Cp_out = d.Cp_out, Kout = d.Kout, act = d.act, cls_cp = d.cls_cp, n_extent = d.n_extent;
+  const int Cp_out = d.Cp_out, Kout = d.Kout, act = d.act, cls_cp = d.cls_cp, n_extent = d.n_extent, stats_slots = d.stats_slots;
 
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
@@ -409,8 +409,12 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (lh == 0 && k < Kout) {
-          atomicAdd(&stats[2 * ((size_t)n * Cp_out + k)], s1);
-          atomicAdd(&stats[2 * ((size_t)n * Cp_out + k) + 1], s2);
+          // per-sample sums, or (layers with hundreds of tiles per sample) this tile's own slot of a partial table:
+          // no contended float atomics, no extra pass over the output
+          float* sp = stats_slots > 0 ? stats + 2 * (((size_t)n * stats_slots + (p_base >> 7)) * Cp_out + k)
+                                      : stats + 2 * ((size_t)n * Cp_out + k);
+          atomicAdd(sp, s1);
+          atomicAdd(sp + 1, s2);
         }
       }
     }

@@ -263,14 +263,27 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   return P2PHD_OK;
 }
 
+// per-tile InstanceNorm sums of a many-tile layer: [N][slots][Cp][2] floats behind the layer's other scratch
+int stat_slots(const std::vector<Plan>& plans) {
+  int slots = 0;
+  for (const auto& p : plans) slots = std::max(slots, (p.d.Hg * p.d.Wg + 127) / 128);
+  return slots;
+}
+size_t stat_table_bytes(const p2phd_conv_desc* c, const std::vector<Plan>& plans) {
+  return align256((size_t)c->N * stat_slots(plans) * cpitch(c->K) * 2 * sizeof(float));
+}
+
 extern "C" size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   const int fold = fold_mode(c);
   if (fold == FOLD_OUT) return folded_dy_bytes(c, Ho, Wo);      // Y has the shape of the folded dy
-  if (fold == FOLD_IN) return folded_x_bytes(c, Wo);
-  return 0;
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, 0, plans, &m);
+  const size_t table = separate_stats(Ho, Wo) ? stat_table_bytes(c, plans) : 0;
+  if (fold == FOLD_IN) return folded_x_bytes(c, Wo) + table;
+  return table;
 }
 
 extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* wp, const float* bias, int act,
@@ -296,19 +309,32 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
     Plan& p = plans[0];
     p.d.act = act;
     const bool sep = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
-    if (int rc = launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, sep ? nullptr : stats, st)) return rc;
-    if (sep) return launch_plane_stats(c->dtype, y, stats, c->N, (long)Ho * Wo, c->K, st);
-    return P2PHD_OK;
+    if (!sep) return launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, stats, st);
+    float* table = reinterpret_cast<float*>(static_cast<char*>(workspace) + folded_x_bytes(c, Wo));
+    const int slots = stat_slots(plans);
+    (void)hipMemsetAsync(table, 0, stat_table_bytes(c, plans), st);
+    p.d.stats_slots = slots;
+    if (int rc = launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, table, st)) return rc;
+    return launch_tile_stats_reduce(table, stats, c->N, slots, cpitch(c->K), st);
   }
   // InstanceNorm sums: in the conv epilogue (float atomics, one per wave and channel) unless a sample spans so many
   // M tiles that thousands of adds would pile onto each (n, channel) address; then a stand-alone pass over y is cheaper
   const bool sep_stats = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
+  float* table = nullptr;
+  int slots = 0;
+  if (sep_stats) {
+    P2PHD_REQUIRE(workspace, "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch (per-tile statistics)");
+    table = static_cast<float*>(workspace);
+    slots = stat_slots(plans);
+    (void)hipMemsetAsync(table, 0, stat_table_bytes(c, plans), st);
+  }
   for (auto& p : plans) {
     p.d.act = act;
+    p.d.stats_slots = slots;
     const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, sep_stats ? nullptr : stats, st)) return rc;
+    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, sep_stats ? table : stats, st)) return rc;
   }
-  if (sep_stats) return launch_plane_stats(c->dtype, y, stats, c->N, (long)Ho * Wo, c->K, st);
+  if (sep_stats) return launch_tile_stats_reduce(table, stats, c->N, slots, cpitch(c->K), st);
   return P2PHD_OK;
 }
 

@@ -19,6 +19,7 @@ struct GDesc {
                                               //      class (pi,pj) = (col / cls_cp) writes output pixel (2*ho+pi, 2*wo+pj)
   int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
+  int stats_slots;                            // > 0: `stats` is a [N][stats_slots][Cp_out][2] table of per-tile sums (slot = first row / 128)
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -56,6 +57,7 @@ int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st);
 
 int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st);
+int launch_tile_stats_reduce(const float* partial, float* stats, int N, int slots, int Cp, hipStream_t st);
 int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,
                      hipStream_t st);
 int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st);

@@ -566,7 +566,36 @@ int stationary_grid(long HW, int cpr, int N) {
 }
 }  // namespace
 
+namespace {
+// stats[n][c][2] += sum over the tile slots of partial[n][slot][c][2] (written by the conv epilogue in stats_slots mode)
+__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, float* __restrict__ stats,
+                                                                int slots, int Cp2, int per) {
+  const int n = blockIdx.y;
+  const int s0 = blockIdx.x * per, s1 = min(slots, s0 + per);
+  for (int c = threadIdx.x; c < Cp2; c += 256) {
+    const float* src = partial + ((size_t)n * slots + s0) * Cp2 + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {
+      a0 += src[0]; a1 += src[(size_t)Cp2]; a2 += src[(size_t)2 * Cp2]; a3 += src[(size_t)3 * Cp2];
+      src += (size_t)4 * Cp2;
+    }
+    for (; s < s1; ++s) { a0 += *src; src += Cp2; }
+    atomicAdd(&stats[(size_t)n * Cp2 + c], (a0 + a1) + (a2 + a3));
+  }
+}
+}  // namespace
+
 namespace p2phd {
+int launch_tile_stats_reduce(const float* partial, float* stats, int N, int slots, int Cp, hipStream_t st) {
+  if (N == 0 || slots == 0) return P2PHD_OK;
+  const int chunks = std::max(1, std::min(slots / 16, 64));
+  const int per = (slots + chunks - 1) / chunks;
+  hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((unsigned)((slots + per - 1) / per), (unsigned)N), dim3(256), 0, st, partial, stats,
+                     slots, 2 * Cp, per);
+  return check_launch("tile_stats_reduce");
+}
+
 int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st) {
   const int Cp = (C + 7) & ~7;
   if (N == 0 || HW == 0) return P2PHD_OK;

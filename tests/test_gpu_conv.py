@@ -35,6 +35,10 @@ CASES = [
     ("kfold_norm_k3", 8, 3, 7, 1, 3, 1, False, 0, True, 3, (2, 14, 19), False),           # output fold + IN statistics
     ("kfold_c4_k4_zero", 4, 4, 3, 1, 1, 0, False, 0, False, 1, (2, 9, 11), False),        # both tiny: output fold, zero pad
     ("cfold_c3_zero", 3, 24, 5, 1, 2, 0, False, 0, True, 3, (1, 11, 13), False),          # input fold, zero pad
+    # planes of > 16384 pixels: InstanceNorm sums go through the per-tile table + reduce instead of per-sample atomics
+    ("bigplane_stats", 8, 16, 3, 1, 1, 0, False, 0, True, 3, (2, 160, 112), False),
+    ("bigplane_cfold", 2, 8, 7, 1, 3, 1, False, 0, True, 3, (1, 136, 128), False),
+    ("bigplane_ct", 16, 8, 3, 2, 1, 0, True, 1, True, 3, (1, 72, 120), False),
 ]
 
 
