@@ -254,3 +254,36 @@ def test_device_state_adam_and_accumulating_entry_points():
                                             Ho * Wo, 40, 1e-5, _ops.ACT_RELU, _lib.stream_ptr()))
     assert rel_err(dy2.cpu().numpy(), dy1.cpu().numpy()) < 1e-5      # the per-(n,c) sums are float atomics: not bit-identical run to run
     assert float((db2 - 3.0 - db1).abs().max()) < 1e-3
+
+
+def test_trunk_layer_at_baseline_size():
+    """The dominant layer at its BASELINE geometry (Conv3x3 768->768 behind ReflectionPad2d(1) on 32x16 planes + InstanceNorm
+    + ReLU): fp32 path against torch-CPU on a 4-sample batch (forward, input / weight gradients), then the full 32-sample
+    bf16 launch (256x192 tiles, 256 workgroups) against the fp32 result of the same samples."""
+    from pix2pixhdaudiosr_amd import _ops
+    g = torch.Generator().manual_seed(11)
+    cin = cout = 768
+    case = ("trunk", cin, cout, 3, 1, 1, 1, False, 0, True, 3, (4, 32, 16), False)
+    x = torch.randn(4, cin, 32, 16, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.02
+    b = torch.randn(cout, generator=g) * 0.1
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yo = _oracle(xo, wo, b, None, case)
+    cot = torch.randn(yo.shape, generator=g)
+    gxo, gwo = torch.autograd.grad((yo * cot).sum(), [xo, wo])
+    spec = _ops.ConvSpec(cin, cout, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    y = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(torch.float32, xd), wd, bd, spec), cout)
+    assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < 1e-4
+    gx, gw = torch.autograd.grad((y * cot.cuda()).sum(), [xd, wd])
+    # through InstanceNorm + ReLU after a 6912-term fp32 reduction: a handful of ReLU masks flip at |y_hat| ~ 1e-6 and the
+    # two fp32 summation orders differ; tolerance 3e-3 relative L2 (element errors ~2e-5 on O(1) values)
+    assert rel_err(gx.cpu().numpy(), gxo.numpy()) < 3e-3
+    assert rel_err(gw.cpu().numpy(), gwo.numpy()) < 3e-3
+    # full batch, bf16 throughput mode: every sample is independent, so samples 0..3 of the 32-sample launch must
+    # reproduce the fp32 result up to bf16 rounding
+    x32 = torch.cat([x, torch.randn(28, cin, 32, 16, generator=g)]).cuda()
+    with torch.no_grad():
+        y32 = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, x32), wd.detach(), bd.detach(), spec), cout)
+    assert tuple(y32.shape) == (32, cout, 32, 16) and torch.isfinite(y32).all()
+    assert rel_err(y32[:4].float().cpu().numpy(), yo.detach().numpy()) < 3e-2
