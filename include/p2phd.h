@@ -129,7 +129,9 @@ int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w,
 
 /* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], zeroed by the caller) the per-(n,channel)
  * sum and sum of squares of conv(x)+bias are accumulated into it (what InstanceNorm2d needs, networks.py:22). */
-size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c);   /* non-zero only for <= 4-channel layers */
+/* scratch of the forward launch: the folded tensor of <= 4-channel layers and, for outputs of more than 16384 pixels per
+ * sample, the per-tile statistics table that a small kernel reduces into `stats`; 0 for every other layer */
+size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_fwd, const float* bias, int act,
                    void* y, float* stats, void* workspace, void* stream);
 
