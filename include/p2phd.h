@@ -79,7 +79,7 @@ int p2phd_imdct4_fwd(const float* spec, int64_t B, int64_t n_frames, int n_fft, 
 /* ------------------------------------------------------------------------------------------
  * MDCT2 / IMDCT2 and the DCT-II / DCT-III operators DCT_2N_native / IDCT_2N_native
  * (models/mdct.py:352-454, dct/dct_native.py:7-68; native counterparts dct/src/dct_2N_cuda.cpp,
- * dct_cuda_kernel.cu:267-406).  n_fft a power of two in [16, 1024]; tables as for MDCT4.
+ * dct_cuda_kernel.cu:267-406).  n_fft a power of two in [16, 2048]; tables as for MDCT4.
  *   forward  out[b,t,k] = scale * c_k * (2/N) * sum_i w[i] xpad[b, t*hop+i] cos(pi (2i+1) k / 2N), c_0 = k0_scale
  *   inverse  y_t[i]     = k0_scale * S[b,t,0] + 2 * sum_{k>=1} S[b,t,k] cos(pi (2i+1) k / 2N);
  *            out[b,m]   = scale * sum_t w[q] y_t[q], q = m + crop_start - t*hop in [0,win)

@@ -10,7 +10,8 @@
 // One workgroup owns a tile of frames of one batch row, exactly like mdct.hip: the signal segment is staged once in
 // LDS, each wavefront runs Makhoul's even/odd reordering + one N-point Stockham FFT in its own LDS buffers + one
 // rotation by exp(-i pi k / 2N); no zero-padded 2N buffer, no separate reorder / twiddle / truncate passes.  The
-// inverse overlap-adds by gather from an LDS ring of time-domain frames.  n_fft a power of two in [16, 1024].
+// inverse overlap-adds by gather from an LDS ring of time-domain frames.  n_fft a power of two in [16, 2048] (at 2048
+// two of the four wavefronts run the FFTs: their buffers are what fits beside the frame ring in 160 KiB).
 #include "common.h"
 #include "fft_wave.h"
 #include <cmath>
@@ -24,7 +25,7 @@ constexpr int kWaves = 4;
 __global__ __launch_bounds__(kThreads) void mdct2_fwd_kernel(
     const float* __restrict__ x, long T, int N, int hop, int win, const float* __restrict__ window,
     const float* __restrict__ tables, long start_pad, long F, float scale, float k0_scale, float* __restrict__ out,
-    int f_tile, int n_tiles, int seg_cap, int win_cap) {
+    int f_tile, int n_tiles, int seg_cap, int win_cap, int fft_waves) {
   extern __shared__ float4 smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,9 +53,9 @@ __global__ __launch_bounds__(kThreads) void mdct2_fwd_kernel(
   __syncthreads();
 
   const float nrm = scale * 2.f / (float)N;
-  for (int f0 = 0; f0 < nf; f0 += kWaves) {
+  for (int f0 = 0; f0 < nf; f0 += fft_waves) {                  // fft_waves < 4 at n_fft 2048: idle waves only keep the barriers
     const int f = f0 + wave;
-    const bool active = f < nf;
+    const bool active = wave < fft_waves && f < nf;
     if (active) {
       const float* u = s_sig + f * hop;
       auto U = [&](int n) -> float { return n < win ? u[n] * s_win[n] : 0.f; };
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void mdct2_fwd_kernel(
 __global__ __launch_bounds__(kThreads) void imdct2_fwd_kernel(
     const float* __restrict__ spec, long F, int N, int hop, int win, const float* __restrict__ window,
     const float* __restrict__ tables, long crop, long out_len, float scale, float k0_scale, float* __restrict__ out,
-    int ts, int n_tiles, int fr_cap, int win_cap) {
+    int ts, int n_tiles, int fr_cap, int win_cap, int fft_waves) {
   extern __shared__ float4 smem_raw[];
   float* smem = reinterpret_cast<float*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -112,9 +113,9 @@ __global__ __launch_bounds__(kThreads) void imdct2_fwd_kernel(
   const int nfr = (int)(t_hi - t_lo + 1);
   __syncthreads();
 
-  for (int f0 = 0; f0 < nfr; f0 += kWaves) {
+  for (int f0 = 0; f0 < nfr; f0 += fft_waves) {
     const int f = f0 + wave;
-    const bool active = f < nfr;
+    const bool active = wave < fft_waves && f < nfr;
     float* X = reinterpret_cast<float*>(buf1);
     if (active) {
       const float* row = spec + ((b * F + t_lo + f) * (long)N);
@@ -160,10 +161,11 @@ __global__ __launch_bounds__(kThreads) void imdct2_fwd_kernel(
 }
 
 int frames_per_tile(int N) { return N <= 256 ? 8 : (N <= 512 ? 4 : 2); }
+int fft_waves_for(int N) { return N <= 1024 ? kWaves : 2; }      // 2 x (2 buffers of N float2) = 64 KiB at N = 2048
 
 int check_common(int n_fft, int hop, int win) {
-  P2PHD_REQUIRE(p2phd::is_pow2(n_fft) && n_fft >= 16 && n_fft <= 1024,
-                "mdct2: n_fft must be a power of two in [16, 1024], got %d", n_fft);
+  P2PHD_REQUIRE(p2phd::is_pow2(n_fft) && n_fft >= 16 && n_fft <= 2048,
+                "mdct2: n_fft must be a power of two in [16, 2048], got %d", n_fft);
   P2PHD_REQUIRE(win >= 1 && win <= n_fft, "mdct2: window length %d should be no more than fft length %d", win, n_fft);
   P2PHD_REQUIRE(hop >= 1 && hop <= win, "mdct2: hop %d exceeds the window (%d): you hopped more than one frame", hop, win);
   return P2PHD_OK;
@@ -174,7 +176,7 @@ int check_common(int n_fft, int hop, int win) {
 extern "C" size_t p2phd_dct_tables_floats(int n_fft) { return 4 * (size_t)n_fft; }
 
 extern "C" int p2phd_dct_tables_fill(int n_fft, float* host_out) {
-  P2PHD_REQUIRE(p2phd::is_pow2(n_fft) && n_fft >= 16 && n_fft <= 1024, "dct tables: bad n_fft %d", n_fft);
+  P2PHD_REQUIRE(p2phd::is_pow2(n_fft) && n_fft >= 16 && n_fft <= 2048, "dct tables: bad n_fft %d", n_fft);
   P2PHD_REQUIRE(host_out != nullptr, "dct tables: null output");
   const double pi = 3.14159265358979323846264338327950288;
   for (int j = 0; j < n_fft; ++j) {
@@ -202,11 +204,13 @@ extern "C" int p2phd_mdct2_fwd(const float* x, int64_t B, int64_t T, int n_fft, 
   P2PHD_REQUIRE(B * n_tiles < (1ll << 31), "mdct2_fwd: grid too large");
   const int seg_cap = (((f_tile - 1) * hop + win) + 3) & ~3;
   const int win_cap = (win + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)seg_cap + win_cap + 4 * n_fft + (size_t)kWaves * 4 * n_fft);
+  const int fw = fft_waves_for(n_fft);
+  const size_t lds = sizeof(float) * ((size_t)seg_cap + win_cap + 4 * n_fft + (size_t)fw * 4 * n_fft);
+  P2PHD_REQUIRE(lds <= 160 * 1024, "mdct2_fwd: hop %d / window %d need %zu B of LDS", hop, win, lds);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mdct2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(mdct2_fwd_kernel, dim3((unsigned)(B * n_tiles)), dim3(kThreads), lds, (hipStream_t)stream, x, (long)T, n_fft, hop,
-                     win, window, tables, (long)start_pad, (long)n_frames, scale, k0_scale, out, f_tile, (int)n_tiles, seg_cap, win_cap);
+                     win, window, tables, (long)start_pad, (long)n_frames, scale, k0_scale, out, f_tile, (int)n_tiles, seg_cap, win_cap, fw);
   return p2phd::check_launch("mdct2_fwd");
 }
 
@@ -223,11 +227,12 @@ extern "C" int p2phd_imdct2_fwd(const float* spec, int64_t B, int64_t n_frames, 
   P2PHD_REQUIRE(B * n_tiles < (1ll << 31), "imdct2_fwd: grid too large");
   const int fr_cap = f_tile + (win - 1) / hop + 1;
   const int win_cap = (win + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)fr_cap * win + win_cap + 4 * n_fft + (size_t)kWaves * 4 * n_fft);
+  const int fw = fft_waves_for(n_fft);
+  const size_t lds = sizeof(float) * ((size_t)fr_cap * win + win_cap + 4 * n_fft + (size_t)fw * 4 * n_fft);
   P2PHD_REQUIRE(lds <= 160 * 1024, "imdct2_fwd: hop %d too small for n_fft %d (LDS frame ring %zu B)", hop, n_fft, lds);
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(imdct2_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(imdct2_fwd_kernel, dim3((unsigned)(B * n_tiles)), dim3(kThreads), lds, (hipStream_t)stream, spec, (long)n_frames,
-                     n_fft, hop, win, window, tables, (long)crop_start, (long)out_len, scale, k0_scale, out, ts, (int)n_tiles, fr_cap, win_cap);
+                     n_fft, hop, win, window, tables, (long)crop_start, (long)out_len, scale, k0_scale, out, ts, (int)n_tiles, fr_cap, win_cap, fw);
   return p2phd::check_launch("imdct2_fwd");
 }

@@ -3,7 +3,7 @@
     DCT_2N_native(x)[k]  = (2/N) * sum_i x[i] cos(pi (2i+1) k / 2N)
     IDCT_2N_native(X)[i] = X[0] + 2 * sum_{k>=1} X[k] cos(pi (2i+1) k / 2N)        (so idct(dct(a)) = 2a)
 
-over the last dimension (a power of two in [16, 1024]); differentiable; GPU only.
+over the last dimension (a power of two in [16, 2048]); differentiable; GPU only.
 """
 import torch
 from torch import nn
@@ -13,8 +13,8 @@ from ..models import mdct as _m
 
 def _rows(x):
     N = x.size(-1)
-    if N < 16 or N > 1024 or (N & (N - 1)):
-        raise NotImplementedError("HIP DCT: last dimension must be a power of two in [16, 1024], got %d" % N)
+    if N < 16 or N > 2048 or (N & (N - 1)):
+        raise NotImplementedError("HIP DCT: last dimension must be a power of two in [16, 2048], got %d" % N)
     if not x.is_cuda:
         raise RuntimeError("HIP DCT runs on the GPU only")
     return x.reshape(-1, N).to(torch.float32).contiguous(), N

@@ -249,8 +249,8 @@ def _check_dct_op(op, kind):
 
 class _Base2(_Base):
     def _setup2(self, n_fft, hop_length, win_length, window, center, pad_mode, device, out_dtype):
-        if n_fft > 1024:
-            raise NotImplementedError("MDCT2/IMDCT2 on the HIP path support n_fft <= 1024, got %d" % n_fft)
+        if n_fft > 2048:
+            raise NotImplementedError("MDCT2/IMDCT2 on the HIP path support n_fft <= 2048, got %d" % n_fft)
         self._setup(n_fft, hop_length, win_length, window, center, pad_mode, device, out_dtype)
 
     def _tables(self):

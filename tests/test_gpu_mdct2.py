@@ -72,4 +72,10 @@ def test_default_geometry_roundtrip():
     y = imdct(S).squeeze().cpu()
     assert float(((y - x) ** 2).mean()) < 1e-9
     with pytest.raises(NotImplementedError):
-        MDCT2(n_fft=2048, hop_length=1024, win_length=2048, window=kbdwin, device="cuda")
+        MDCT2(n_fft=4096, hop_length=2048, win_length=4096, window=kbdwin, device="cuda")
+    # the reference's class default (n_fft 2048): round trip at that size too
+    x2 = 0.1 * torch.randn(3, 16 * 1024, generator=torch.Generator().manual_seed(4))
+    S2 = MDCT2(n_fft=2048, hop_length=1024, win_length=2048, window=kbdwin, device="cuda")(x2.cuda())
+    assert tuple(S2.shape) == (3, 17, 2048)
+    y2 = IMDCT2(n_fft=2048, hop_length=1024, win_length=2048, window=kbdwin, device="cuda", out_length=16 * 1024)(S2).squeeze().cpu()
+    assert float(((y2 - x2) ** 2).mean()) < 1e-9

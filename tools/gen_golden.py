@@ -142,7 +142,7 @@ def gen_mdct2(out):
     cases = [("n16_b3", 16, 8, 16, (3, 72), True), ("n64_b2_odd", 64, 32, 64, (2, 470), True),
              ("n64_hop16", 64, 16, 64, (2, 480), True), ("n64_win48", 64, 24, 48, (2, 480), True),
              ("n64_nocenter", 64, 32, 64, (2, 480), False), ("n512_b2", 512, 256, 512, (2, 7 * 256), True),
-             ("n1024_b1", 1024, 512, 1024, (1, 5 * 512), True)]
+             ("n1024_b1", 1024, 512, 1024, (1, 5 * 512), True), ("n2048_b1", 2048, 1024, 2048, (1, 4 * 1024), True)]
     meta = []
     for name, n_fft, hop, win, shape, center in cases:
         x = (torch.randn(*shape, generator=g) * 0.1).requires_grad_(True)
