@@ -57,12 +57,18 @@ def time_trunk_conv(batch, iters=20):
     L = _ops.lib()
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
                                                None, _ops.stream_ptr()))
+    sec = time_graphed(call, iters)
+    flops = 2.0 * batch * 32 * 16 * 768 * 768 * 9
+    return sec, flops
+
+
+def time_graphed(call, iters=20):
+    """Average duration of one `call()` (a chain of launches on the current stream): `iters` repetitions captured into
+    one HIP graph, HIP events around a replay.  Consecutive graph nodes start within ~1-2 us of each other, so
+    elapsed / iters is kernel time (agrees with rocprofv3's per-kernel average)."""
     for _ in range(3):
         call()
     torch.cuda.synchronize()
-    # the `iters` launches are replayed from a captured graph, like the step itself: consecutive graph nodes start
-    # within ~1-2 us of each other, so (elapsed / iters) is the kernel's duration and agrees with rocprofv3's
-    # per-kernel average (eager ctypes launches add a ~15 us dispatch gap per launch to a start-to-start figure)
     graph = torch.cuda.CUDAGraph()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -73,15 +79,45 @@ def time_trunk_conv(batch, iters=20):
         graph.capture_end()
     torch.cuda.current_stream().wait_stream(side)
     graph.replay()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    graph.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * batch * 32 * 16 * 768 * 768 * 9
-    return sec, flops
+    best = None
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        graph.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        sec = e0.elapsed_time(e1) / 1e3 / iters
+        best = sec if best is None else min(best, sec)
+    return best
+
+
+HBM_PEAK_TBS = 8.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s float4-copy achievable)
+
+
+def time_mdct(batch):
+    """MDCT4 and IMDCT4 alone: frames/s and GB/s on the algorithmic bytes (read hop + write n_fft/2 floats
+    per frame = 4 KiB at n_fft 1024, 8 KiB at 2048), at the configs[1] geometry [B, 130560] and at n_fft 2048."""
+    from pix2pixhdaudiosr_amd.models import mdct as MM
+    from pix2pixhdaudiosr_amd.util.util import kbdwin
+    out = {}
+    for n_fft, frames in ((1024, 256), (2048, 512)):
+        hop = n_fft // 2
+        T = (frames - 1) * hop
+        w = kbdwin(n_fft).cuda()
+        tables = MM._Tables.get(n_fft, w.device)
+        x = 0.1 * torch.randn(batch, T, device="cuda")
+        sp, _, nf = MM.frame_layout(batch, T, hop, n_fft, True)
+        S = MM._run_mdct(x, n_fft, hop, n_fft, w, tables, sp, nf, 1.0)
+        t_f = time_graphed(lambda: MM._run_mdct(x, n_fft, hop, n_fft, w, tables, sp, nf, 1.0))
+        t_i = time_graphed(lambda: MM._run_imdct(S, n_fft, hop, n_fft, w, tables, n_fft // 2, T, 4.0 / n_fft))
+        nframes = batch * nf
+        bytes_alg = nframes * 2 * n_fft          # (hop + n_fft/2) floats = 2 n_fft bytes per frame
+        for name, t in (("mdct4", t_f), ("imdct4", t_i)):
+            out[f"{name}_n{n_fft}"] = {"shape": [batch, T], "frames": nframes, "us": t * 1e6, "frames_per_s": nframes / t,
+                                       "GB_per_s": bytes_alg / t / 1e9, "frac_of_hbm_peak": bytes_alg / t / 1e12 / HBM_PEAK_TBS,
+                                       "bytes_per_frame": 2 * n_fft}
+    return out
 
 
 def host_cores():
@@ -113,6 +149,32 @@ def cpu_baseline(sample_batch=2, steps=4):
                       f"{steps} timed step(s), fp32, {dt:.2f} s/step"}
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher around it: THIS process has not touched the GPU yet (importing
+    torch does not), so it starts one rank per GPU through torch.distributed.run as child processes, relays rank 0's
+    JSON line and exits with the launcher's code.  Never an exec of a process that initialised HIP."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")             # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env)
+    try:
+        rc = proc.wait()
+    except KeyboardInterrupt:
+        proc.terminate()
+        rc = proc.wait()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -121,11 +183,23 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager step on one GPU too (default: captured HIP graph)")
+    ap.add_argument("--allow-eager-fallback", action="store_true",
+                    help="keep measuring with the eager step if graph capture / replay fails (default: exit non-zero)")
+    ap.add_argument("--no-mdct", action="store_true", help="skip the stand-alone MDCT4 / IMDCT4 measurement")
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if a.gpus > 1:
+            launch_ranks(a.gpus, sys.argv[1:])                     # does not return
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != a.gpus:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # rehearsal hooks (never set by the driver): run several ranks on one GPU over gloo to exercise the DP code path
     backend = os.environ.get("P2PHD_DIST_BACKEND", "nccl")
     if "P2PHD_FORCE_DEVICE" in os.environ:
@@ -164,18 +238,29 @@ def main():
     # The step is captured once into HIP graphs and replayed (same kernels, same order, no host work per step); with
     # data parallelism the two RCCL all-reduces run between the replays, the G one overlapping the D backward.
     graphed = not a.no_graph
+    graph_error = None
     step = model.train_step_graphed if graphed else model.train_step
+
+    def graph_failed(what, e):
+        # a failed capture / replay leaves the side stream and the graph pool in an undefined state: the measurement is
+        # only continued (eagerly) on request, and the JSON line then says so
+        nonlocal graphed, step, graph_error
+        graph_error = f"{what}: {type(e).__name__}: {e}"
+        log(graph_error)
+        if not a.allow_eager_fallback:
+            raise SystemExit(f"bench.py: {graph_error} (pass --allow-eager-fallback or --no-graph to measure the eager step)")
+        graphed, step = False, model.train_step
+        model._graph_state = None
+        torch.cuda.synchronize()
+
     if graphed:
         try:
             for _ in range(3):                                     # two eager steps + capture, before the warm-up steps
                 step(lr, hr)
             torch.cuda.synchronize()
             log("step captured into HIP graphs (forward + G backward | D backward | Adam), collectives between replays")
-        except Exception as e:                                     # keep the measurement: fall back to the eager step
-            log(f"graph capture failed ({type(e).__name__}: {e}); running the eager step")
-            graphed, step = False, model.train_step
-            model._graph_state = None
-            torch.cuda.synchronize()
+        except Exception as e:
+            graph_failed("graph capture failed", e)
     for i in range(a.warmup):
         try:
             step(lr, hr)
@@ -183,9 +268,7 @@ def main():
         except Exception as e:
             if not graphed:
                 raise
-            log(f"graph replay failed in warm-up ({type(e).__name__}: {e}); running the eager step")
-            graphed, step = False, model.train_step
-            model._graph_state = None
+            graph_failed("graph replay failed in warm-up", e)
             step(lr, hr)
             torch.cuda.synchronize()
         log(f"warm-up step {i} done")
@@ -195,10 +278,18 @@ def main():
         step(lr, hr)
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = [dt / a.steps * 1e3]
+    dist_info = None
     if world > 1:
+        import torch.distributed as dist
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(v.item()) / a.steps * 1e3 for v in every]
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                     "devices": sorted({local}) if "P2PHD_FORCE_DEVICE" in os.environ else list(range(world))}
 
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -215,17 +306,29 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "launch": "hip-graph replay" if graphed else "eager",
                        "step_tflops_per_gpu": step_flops / (dt / a.steps) / 1e12,
-                       "step_frac_of_bf16_peak": step_flops / (dt / a.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS},
+                       "step_frac_of_bf16_peak": step_flops / (dt / a.steps) / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                       "step_flops_model": "algorithmic unit of SURVEY 8(d): (6 M_G + 16 M_D) FLOP per sample; the shared "
+                                           "D(fake) forward executes ~3.5 % fewer"},
+            "per_rank_ms_per_step": rank_ms,
         }
+        if dist_info is not None:
+            out["dist"] = dist_info
+        if graph_error is not None:
+            out["graph_error"] = graph_error
         log(f"timed region done: {ms:.1f} ms/step")
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
         # from the separate rocprofv3 --pmc passes recorded in profiles/ (same kernel, same shapes, per launch)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_trunk_pmc.json")) as f:
-                traffic = json.load(f)["hbm_bytes_per_launch"] if a.batch == 32 else None
-        except Exception:
-            traffic = None
+        traffic, traffic_source = None, None
+        for name in ("r02_trunk_pmc.json", "r01_trunk_pmc.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    rec = json.load(f)
+                if a.batch == 32:
+                    traffic = rec["hbm_bytes_per_launch"]
+                    traffic_source = {"file": "profiles/" + name, "recorded": rec.get("recorded"), "how": rec.get("how")}
+                break
+            except Exception:
+                continue
         # Dominant kernel, timed live INSIDE a step: HIP events on the launch stream around each of the 18 trunk-conv
         # launches of two extra eager steps (the graph-replayed steps above run exactly these kernels).  The
         # stand-alone back-to-back figure is logged too: 20 MFMA-bound launches in a row run at a lower sustained clock.
@@ -249,14 +352,18 @@ def main():
             _ops._KERNEL_PROBE["events"] = []
         log(f"trunk conv {sec * 1e6:.1f} us/launch")
         out["roofline"] = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic,
+                           "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": "gconv_kernel<bf16> implicit-GEMM Conv3x3 768->768 @32x16 (residual trunk, 18 of 28 generator convs)",
                            "launch_us": sec * 1e6, "flops_per_launch": flops}
+        if world == 1 and not a.no_mdct:
+            out["mdct"] = time_mdct(a.batch)
+            log("mdct alone: " + ", ".join(f"{k} {v['us']:.1f} us {v['GB_per_s']:.0f} GB/s" for k, v in out["mdct"].items()))
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle, batch 2, 4 steps) ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()                               # rank 0 is still measuring its dominant kernel
         torch.distributed.destroy_process_group()
 
 

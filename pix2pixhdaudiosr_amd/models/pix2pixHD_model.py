@@ -382,6 +382,10 @@ class Pix2PixHDModel(BaseModel):
         gC.replay()
         optG.step_count += 1
         optD.step_count += 1
+        # the replayed Adam changed the master weights behind the host's back: packed copies cached by ConvSpec are stale
+        # for any EAGER call that follows (inference / forward / train_step between replays).  Graph A re-packs into the
+        # same buffers by itself, so the replay path is unaffected by the bump.
+        _ops.bump_weight_epoch()
         return st['out']
 
     def save(self, which_epoch):

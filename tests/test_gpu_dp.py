@@ -44,3 +44,24 @@ def test_two_ranks_one_gpu(tmp_path, mode):
             d = (r0["first"][k] - s[k]).abs()
             assert float(d.max()) <= 4.5e-4, (k, float(d.max()))
             assert float((d > 1e-5).float().mean()) < 0.05, (k, float((d > 1e-5).float().mean()))
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start two ranks itself (before touching the GPU) and
+    print ONE JSON line with n_gpus == 2.  Rehearsal environment: both ranks on the box's one GPU, gloo between them."""
+    import json
+    env = dict(os.environ, P2PHD_DIST_BACKEND="gloo", P2PHD_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["dist"]["ranks"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out
+    assert out["value"] > 0 and out["scaling"] == "weak"
+
