@@ -42,7 +42,13 @@ CASES = [
 ]
 
 
-def _oracle(x, w, b, res, c):
+SLOPE = {1: 0.2, 3: 0.0}
+
+
+def _oracle(x, w, b, res, c, mask=None):
+    """The layer with torch-CPU fp32 functional ops.  `mask` (bool, output shape): take the (Leaky)ReLU branch decision
+    from the candidate's own output instead of from this computation's sign -- the two differ only where the
+    pre-activation is within rounding of zero, and there a different branch is not an error of the candidate."""
     name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, _, _ = c
     if transposed:
         y = F.conv_transpose2d(x, w, b, stride=stride, padding=pad, output_padding=opad)
@@ -52,30 +58,31 @@ def _oracle(x, w, b, res, c):
         y = F.conv2d(x, w, b, stride=stride, padding=pad)
     if norm:
         y = F.instance_norm(y, eps=1e-5)
-    y = ACT[act](y)
+    if mask is not None and act in SLOPE:
+        y = y * torch.where(mask, torch.ones(()), torch.full((), SLOPE[act]))
+    else:
+        y = ACT[act](y)
     if res is not None:
         y = y + res
     return y
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 3e-2)])
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv_block(case, dtype, tol):
+def conv_case_errors(case, dtype, seed):
+    """Run one layer on the HIP path and against the oracle; returns {quantity: relative L2 error}.
+    fp32: oracle on the same fp32 operands.  bf16: the oracle gets what the kernels actually consume -- x, w and the
+    residual rounded to bf16 (bias and accumulation stay fp32) -- and the activation branch of every element from the
+    HIP output, so what remains is accumulation order, the bf16 rounding of the stored intermediates (y, dy) and of the
+    output, NOT the quantisation of the inputs or a (Leaky)ReLU branch that flipped at |pre-activation| ~ 1e-3."""
     from pix2pixhdaudiosr_amd import _ops
     name, cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act, (N, H, W), use_res = case
-    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)   # stable across processes (hash() is salted)
+    g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, cin, H, W, generator=g)
     wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
     w = torch.randn(wshape, generator=g) * 0.1
     b = torch.randn(cout, generator=g) * 0.1
-    xo, wo, bo = (t.clone().requires_grad_(True) for t in (x, w, b))
-    res_o = None
     yo_shape = _oracle(x, w, b, None, case).shape
-    if use_res:
-        res_o = torch.randn(yo_shape, generator=g).requires_grad_(True)
-    yo = _oracle(xo, wo, bo, res_o, case)
-    cot = torch.randn(yo.shape, generator=g)
-    gro = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo] + ([res_o] if use_res else []))
+    res = torch.randn(yo_shape, generator=g) if use_res else None
+    cot = torch.randn(yo_shape, generator=g)
 
     spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, transposed, opad, norm, act)
     xd = x.cuda().requires_grad_(True)
@@ -84,22 +91,62 @@ def test_conv_block(case, dtype, tol):
     xp = _ops.ToPhysical.apply(dtype, xd)
     rp = None
     if use_res:
-        rd = res_o.detach().cuda().requires_grad_(True)
+        rd = res.cuda().requires_grad_(True)
         rp = _ops.ToPhysical.apply(dtype, rd)
     yp = _ops.conv_block(xp, wd, bd, spec, rp)
     assert yp.shape[-1] == _ops.cpitch(cout)
-    assert float(yp[..., cout:].float().abs().max()) == 0.0 if yp.shape[-1] > cout else True   # pad channels stay zero
+    if yp.shape[-1] > cout:
+        assert float(yp.detach()[..., cout:].float().abs().max()) == 0.0      # pad channels stay zero
     y = _ops.FromPhysical.apply(yp, cout)
-    assert tuple(y.shape) == tuple(yo.shape)
-    assert rel_err(y.detach().cpu().numpy(), yo.detach().numpy()) < tol, name
+    assert tuple(y.shape) == tuple(yo_shape)
     grd = torch.autograd.grad((y * cot.cuda()).sum(), [xd, wd, bd] + ([rd] if use_res else []))
-    gt = tol * 3 if dtype == torch.float32 else 0.2      # bf16: two roundings + InstanceNorm cancellation on tiny planes
-    assert rel_err(grd[0].cpu().numpy(), gro[0].numpy()) < gt, name + " dgrad"
-    assert_grad_close(name + ".weight", grd[1].cpu().numpy(), gro[1].numpy(), rtol=gt)
-    if not (norm and dtype == torch.bfloat16):   # bias in front of InstanceNorm: true gradient 0, bf16 leaves only noise
-        assert_grad_close(name + ".bias", grd[2].cpu().numpy(), gro[2].numpy(), rtol=gt, bias_floor=2e-2 if norm else 1e-6 + gt)
+
+    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    xo, wo, bo = (t.clone().requires_grad_(True) for t in (q(x), q(w), b))
+    res_o = q(res).clone().requires_grad_(True) if use_res else None
+    mask = (y.detach().cpu() > 0) if act in SLOPE else None
+    yo = _oracle(xo, wo, bo, res_o, case, mask)
+    gro = torch.autograd.grad((yo * cot).sum(), [xo, wo, bo] + ([res_o] if use_res else []))
+    err = {"y": rel_err(y.detach().cpu().numpy(), yo.detach().numpy()),
+           "dx": rel_err(grd[0].cpu().numpy(), gro[0].numpy()),
+           "dw": rel_err(grd[1].cpu().numpy(), gro[1].numpy()),
+           "db_abs": float(np.linalg.norm(grd[2].cpu().numpy() - gro[2].numpy())),
+           "db_ref": float(np.linalg.norm(gro[2].numpy()))}
     if use_res:
-        assert rel_err(grd[3].cpu().numpy(), gro[3].numpy()) < gt
+        err["dres"] = rel_err(grd[3].cpu().numpy(), gro[3].numpy())
+    if mask is not None:
+        plain = _oracle(xo.detach(), wo.detach(), bo.detach(), None if res_o is None else res_o.detach(), case)
+        err["flips"] = int(((plain - (0 if res_o is None else res_o.detach())) > 0).ne(mask).sum())
+    return err
+
+
+# Tolerances (relative L2 unless noted).  fp32: north_star's 1e-4 on activations, 3e-4 on gradients.  bf16 (the
+# throughput mode): the oracle consumes the same bf16-rounded operands and the candidate's own activation branches
+# (conv_case_errors), so the bound covers only the bf16 rounding of stored intermediates and accumulation order --
+# measured over 20 seeds per case with tools/probe_conv_errors.py (profiles/r02_conv_error_table.txt), bound = 3x the
+# worst seen.  Layers with InstanceNorm on planes of <= 30 pixels amplify a bf16 rounding of y by 1/sigma: separate bound.
+TOL = {torch.float32: dict(y=1e-4, g=3e-4, g_tiny=3e-4), torch.bfloat16: dict(y=1e-2, g=3e-2, g_tiny=1e-1)}
+TINY_PLANES = {"c3_reflect_in_relu", "c3_reflect_in_res", "c3_reflect_2x2", "c4_s1_in_lrelu"}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_block(case, dtype):
+    name, norm = case[0], case[9]
+    t = TOL[dtype]
+    e = conv_case_errors(case, dtype, zlib.crc32(name.encode()) % 1000)   # stable across processes (hash() is salted)
+    gt = t["g_tiny"] if name in TINY_PLANES else t["g"]
+    assert e["y"] < t["y"], (name, e)
+    assert e["dx"] < gt, (name, e)
+    assert e["dw"] < gt, (name, e)
+    if "dres" in e:
+        assert e["dres"] < gt, (name, e)
+    if norm:
+        # bias in front of InstanceNorm: the true gradient is exactly 0 and both sides hold rounding noise of the size
+        # of one dy element's rounding x sqrt(pixels)
+        assert e["db_abs"] < (2e-2 if dtype == torch.float32 else 0.5), (name, e)
+    else:
+        assert e["db_abs"] <= gt * e["db_ref"] + 1e-6, (name, e)
 
 
 @pytest.mark.parametrize("bm", [128, 256, 192, 512])

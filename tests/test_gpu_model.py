@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, assert_grad_close
+from conftest import rel_err, assert_grad_close, noise_bias_keys
 
 pytestmark = pytest.mark.gpu
 
@@ -68,12 +68,15 @@ def test_forward_losses_grads_and_step(golden_model):
     loss_D = (got["D_fake"] + got["D_real"]) * 0.5
     loss_G = got["G_GAN"] + got["G_GAN_Feat"]
     m.optimizer_G.zero_grad(); loss_G.backward(); 
+    nbG = noise_bias_keys([k for k, _ in m.netG.named_parameters()])
+    nbD = noise_bias_keys([k for k, _ in m.netD.named_parameters()])
+    assert len(nbD) == 2 * 3                                      # 2 scales x (5 convs - first - last)
     for k, p in m.netG.named_parameters():
-        assert_grad_close("G:" + k, p.grad.cpu().numpy(), g[f"G_g_{k}"], rtol=5e-4)
+        assert_grad_close("G:" + k, p.grad.cpu().numpy(), g[f"G_g_{k}"], rtol=5e-4, noise_biases=nbG)
     m.optimizer_G.step()
     m.optimizer_D.zero_grad(); loss_D.backward()
     for k, p in m.netD.named_parameters():
-        assert_grad_close("D:" + k, p.grad.cpu().numpy(), g[f"D_g_{k}"], rtol=5e-4)
+        assert_grad_close("D:" + k, p.grad.cpu().numpy(), g[f"D_g_{k}"], rtol=5e-4, noise_biases=nbD)
     m.optimizer_D.step()
     # Adam moves every weight by ~lr on step 1 (sign-like update): compare the update direction where the
     # reference gradient is clearly non-zero, and the magnitude everywhere
@@ -288,3 +291,47 @@ def test_stale_forward_is_refused(golden_model):
     ld = dict(zip(m.loss_names, losses1))
     with pytest.raises(_lib.P2PHDError):
         (ld['G_GAN'] + ld['G_GAN_Feat']).backward()
+
+
+def test_amp_call_sequence_of_train_py(golden_model):
+    """train.py:148-181 with --fp16, verbatim call sequence: forward under autocast(), GradScaler.scale(loss).backward(),
+    scaler.step(optimizer) for G then D, scaler.update() -- against the same model stepped without a scaler.  --fp16 here
+    means bf16 MFMA compute with fp32 master weights (exponent range of fp32: the 65536x loss scale is harmless), and
+    FlatAdam's gradients are views of one flat buffer that the scaler un-scales in place."""
+    from torch.cuda.amp import autocast, GradScaler
+    g = golden_model
+    lr, hr, noise = (torch.from_numpy(g[k]) for k in ("lr", "hr", "mask_noise"))
+    a, b = _model(g, fp16=True), _model(g, fp16=True)
+    # --- a: the reference's AMP sequence
+    scaler = GradScaler()
+    with autocast():
+        losses, _ = a.forward(lr, None, hr, None, noise=noise)
+    ld = dict(zip(a.loss_names, losses))
+    loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
+    loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0)
+    a.optimizer_G.zero_grad()
+    scaler.scale(loss_G).backward()
+    gG_scaled = a.optimizer_G.flat_g.clone()
+    scaler.step(a.optimizer_G)
+    a.optimizer_D.zero_grad()
+    scaler.scale(loss_D).backward()
+    scaler.step(a.optimizer_D)
+    scaler.update()
+    assert scaler.get_scale() == 65536.0                           # no inf / nan was found: both steps were applied
+    assert a.optimizer_G.steps_taken() == 1 and a.optimizer_D.steps_taken() == 1
+    # --- b: plain sequence
+    losses_b, _ = b.forward(lr, None, hr, None, noise=noise)
+    lb = dict(zip(b.loss_names, losses_b))
+    b.optimizer_G.zero_grad(); (lb['G_GAN'] + lb['G_GAN_Feat']).backward()
+    gG = b.optimizer_G.flat_g.clone()
+    b.optimizer_G.step()
+    b.optimizer_D.zero_grad(); ((lb['D_fake'] + lb['D_real']) * 0.5).backward(); b.optimizer_D.step()
+    for k in ld:
+        assert abs(float(ld[k]) - float(lb[k])) <= 1e-4 * max(1.0, abs(float(lb[k]))), k
+    # the scaled backward carried exactly 65536 x the gradient (power of two: same bf16 / fp32 mantissas)
+    assert float((gG_scaled / 65536.0 - gG).norm() / gG.norm()) < 1e-3
+    # after un-scaling, Adam saw the same gradients: weights agree wherever the gradient is not rounding noise
+    for oa, ob, gr in ((a.optimizer_G, b.optimizer_G, gG),):
+        strong = gr.abs() > 1e-2 * gr.abs().max()
+        assert float((oa.flat_p - ob.flat_p).abs()[strong].max()) <= 2e-6
+    assert all(torch.isfinite(p).all() for p in a.parameters())

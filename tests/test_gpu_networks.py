@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err, assert_grad_close, cosine
+from conftest import rel_err, assert_grad_close, cosine, noise_bias_keys
 
 pytestmark = pytest.mark.gpu
 
@@ -31,8 +31,9 @@ def _check_grads(tag, dtype, gtol, names, grads, gx_ref, g):
     signal and skip conv biases in front of InstanceNorm (true gradient exactly 0, pure rounding noise)."""
     if dtype == torch.float32:
         assert rel_err(grads[0].cpu().numpy(), gx_ref) < gtol
+        nb = noise_bias_keys(names)
         for k, gr in zip(names, grads[1:]):
-            assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol)
+            assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol, noise_biases=nb)
     else:
         assert cosine(grads[0].cpu().numpy(), gx_ref) > 0.85
         for k, gr in zip(names, grads[1:]):

@@ -62,3 +62,17 @@ def test_roundtrip_pins():
         assert S.shape == (257, 512)
         y = M.imdct4_forward(S[None], 1024, 512, 1024, w).reshape(-1)
         assert np.mean((y[: x.size] - x) ** 2) < bound
+
+
+def test_product_kbdwin_against_reference(golden_mdct):
+    """util.util.kbdwin of the PRODUCT (a host constant the kernels read) against the reference's own windows
+    (util/util.py:186-192 run by tools/gen_golden.py), directly -- not only through the transforms that use it."""
+    from pix2pixhdaudiosr_amd.util.util import kbdwin
+    for n in (16, 48, 64, 512, 1024, 2048):
+        ref = golden_mdct[f"kbdwin_{n}"]
+        got = kbdwin(n)
+        assert got.dtype.is_floating_point and tuple(got.shape) == ref.shape
+        assert np.max(np.abs(got.numpy().astype(np.float64) - ref.astype(np.float64))) <= 2e-7, n
+        # Princen-Bradley: w[n]^2 + w[n + N/2]^2 == 1
+        w = got.double().numpy()
+        assert np.max(np.abs(w[: n // 2] ** 2 + w[n // 2:] ** 2 - 1.0)) < 1e-6

@@ -3,7 +3,7 @@ outputs, input/parameter gradients, state_dict key order and parameter-count KAT
 import numpy as np
 import torch
 
-from conftest import rel_err, assert_grad_close
+from conftest import rel_err, assert_grad_close, noise_bias_keys
 from oracle import networks as N
 
 TOL = 2e-5   # fp32 CPU vs fp32 CPU, different op grouping only
@@ -24,8 +24,9 @@ def _check_G(g, tag, spec, fwd):
     assert rel_err(y.detach().numpy(), g[f"{tag}_y"]) < TOL
     grads = torch.autograd.grad((y * torch.from_numpy(g[f"{tag}_cot"])).sum(), [x] + list(p.values()))
     assert rel_err(grads[0].numpy(), g[f"{tag}_gx"]) < 1e-4
+    nb = noise_bias_keys(keys)
     for k, gr in zip(keys, grads[1:]):
-        assert_grad_close(f"{tag}:{k}", gr.numpy(), g[f"{tag}_g_{k}"])
+        assert_grad_close(f"{tag}:{k}", gr.numpy(), g[f"{tag}_g_{k}"], noise_biases=nb)
 
 
 def test_global_generator(golden_networks):
@@ -61,8 +62,10 @@ def test_discriminator(golden_networks):
             tot = tot + (f * torch.from_numpy(g[f"{tag}_c{i}"])).sum()
         grads = torch.autograd.grad(tot, [x] + list(p.values()))
         assert rel_err(grads[0].numpy(), g[f"{tag}_gx"]) < 1e-4
+        nb = noise_bias_keys(keys)
+        assert len(nb) == 2 * 3
         for k, gr in zip(keys, grads[1:]):
-            assert_grad_close(f"{tag}:{k}", gr.numpy(), g[f"{tag}_g_{k}"])
+            assert_grad_close(f"{tag}:{k}", gr.numpy(), g[f"{tag}_g_{k}"], noise_biases=nb)
 
 
 def test_gan_loss_kat(golden_networks):
