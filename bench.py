@@ -112,11 +112,11 @@ def time_mdct(batch):
         t_f = time_graphed(lambda: MM._run_mdct(x, n_fft, hop, n_fft, w, tables, sp, nf, 1.0))
         t_i = time_graphed(lambda: MM._run_imdct(S, n_fft, hop, n_fft, w, tables, n_fft // 2, T, 4.0 / n_fft))
         nframes = batch * nf
-        bytes_alg = nframes * 2 * n_fft          # (hop + n_fft/2) floats = 2 n_fft bytes per frame
+        bytes_alg = nframes * 4 * n_fft          # (hop + n_fft/2) floats = 4 n_fft bytes per frame (4 KiB at n_fft 1024)
         for name, t in (("mdct4", t_f), ("imdct4", t_i)):
             out[f"{name}_n{n_fft}"] = {"shape": [batch, T], "frames": nframes, "us": t * 1e6, "frames_per_s": nframes / t,
                                        "GB_per_s": bytes_alg / t / 1e9, "frac_of_hbm_peak": bytes_alg / t / 1e12 / HBM_PEAK_TBS,
-                                       "bytes_per_frame": 2 * n_fft}
+                                       "bytes_per_frame": 4 * n_fft}
     return out
 
 

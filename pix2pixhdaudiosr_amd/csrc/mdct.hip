@@ -242,6 +242,8 @@ extern "C" int p2phd_mdct4_fwd(const float* x, int64_t B, int64_t T, int n_fft, 
   P2PHD_REQUIRE(B >= 0 && T >= 0 && n_frames >= 0 && start_pad >= 0, "mdct4_fwd: negative size");
   if (B == 0 || n_frames == 0) return P2PHD_OK;
   P2PHD_REQUIRE(x && window && tables && out, "mdct4_fwd: null pointer");
+  if (p2phd::mdct4_fast_ok(n_fft, hop, win, T, start_pad, x, out))
+    return p2phd::mdct4_fast_fwd(x, B, T, n_fft, window, tables, start_pad, n_frames, scale, out, (hipStream_t)stream);
   const int f_tile = frames_per_tile(n_fft);
   const int64_t n_tiles = p2phd::cdiv(n_frames, f_tile);
   P2PHD_REQUIRE(B * n_tiles < (1ll << 31), "mdct4_fwd: grid too large");
@@ -264,6 +266,8 @@ extern "C" int p2phd_imdct4_fwd(const float* spec, int64_t B, int64_t n_frames, 
   P2PHD_REQUIRE(B >= 0 && n_frames >= 0 && out_len >= 0 && crop_start >= 0, "imdct4_fwd: negative size");
   if (B == 0 || out_len == 0) return P2PHD_OK;
   P2PHD_REQUIRE(window && tables && out && (spec || n_frames == 0), "imdct4_fwd: null pointer");
+  if (n_frames > 0 && p2phd::mdct4_fast_ok(n_fft, hop, win, out_len, crop_start, spec, out))
+    return p2phd::imdct4_fast(spec, B, n_frames, n_fft, window, tables, crop_start, out_len, scale, out, (hipStream_t)stream);
   const int f_tile = frames_per_tile(n_fft);
   const int ts = f_tile * hop;
   const int64_t n_tiles = p2phd::cdiv(out_len, ts);

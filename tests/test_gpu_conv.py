@@ -111,7 +111,7 @@ def conv_case_errors(case, dtype, seed):
            "dx": rel_err(grd[0].cpu().numpy(), gro[0].numpy()),
            "dw": rel_err(grd[1].cpu().numpy(), gro[1].numpy()),
            "db_abs": float(np.linalg.norm(grd[2].cpu().numpy() - gro[2].numpy())),
-           "db_ref": float(np.linalg.norm(gro[2].numpy()))}
+           "db_ref": float(np.linalg.norm(gro[2].numpy())), "out_elems": int(yo.numel())}
     if use_res:
         err["dres"] = rel_err(grd[3].cpu().numpy(), gro[3].numpy())
     if mask is not None:
@@ -123,10 +123,14 @@ def conv_case_errors(case, dtype, seed):
 # Tolerances (relative L2 unless noted).  fp32: north_star's 1e-4 on activations, 3e-4 on gradients.  bf16 (the
 # throughput mode): the oracle consumes the same bf16-rounded operands and the candidate's own activation branches
 # (conv_case_errors), so the bound covers only the bf16 rounding of stored intermediates and accumulation order --
-# measured over 20 seeds per case with tools/probe_conv_errors.py (profiles/r02_conv_error_table.txt), bound = 3x the
-# worst seen.  Layers with InstanceNorm on planes of <= 30 pixels amplify a bf16 rounding of y by 1/sigma: separate bound.
-TOL = {torch.float32: dict(y=1e-4, g=3e-4, g_tiny=3e-4), torch.bfloat16: dict(y=1e-2, g=3e-2, g_tiny=1e-1)}
-TINY_PLANES = {"c3_reflect_in_relu", "c3_reflect_in_res", "c3_reflect_2x2", "c4_s1_in_lrelu"}
+# measured over 20 seeds per case with tools/probe_conv_errors.py (profiles/r02_conv_error_table.txt: worst y 3.5e-3,
+# gradients 3.5e-3, 8e-3 on the 2x2 plane), bound = 3x the worst seen.
+# Bias gradients are column sums of dy over all pixels: their rounding noise grows like sqrt(pixels x channels), so the
+# absolute floor does too (coefficient = 3x the worst seen); a bias in front of InstanceNorm has a true gradient of
+# exactly 0 and holds ONLY that noise, on both sides.
+TOL = {torch.float32: dict(y=1e-4, g=3e-4, g_tiny=3e-4, db=1e-6, db_norm=1e-4),
+       torch.bfloat16: dict(y=1e-2, g=1.2e-2, g_tiny=2.5e-2, db=8e-3, db_norm=2.5e-2)}
+TINY_PLANES = {"c3_reflect_2x2"}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
@@ -141,12 +145,11 @@ def test_conv_block(case, dtype):
     assert e["dw"] < gt, (name, e)
     if "dres" in e:
         assert e["dres"] < gt, (name, e)
+    noise = np.sqrt(e["out_elems"])                                # sqrt(pixels x channels)
     if norm:
-        # bias in front of InstanceNorm: the true gradient is exactly 0 and both sides hold rounding noise of the size
-        # of one dy element's rounding x sqrt(pixels)
-        assert e["db_abs"] < (2e-2 if dtype == torch.float32 else 0.5), (name, e)
+        assert e["db_abs"] <= t["db_norm"] * noise, (name, e)
     else:
-        assert e["db_abs"] <= gt * e["db_ref"] + 1e-6, (name, e)
+        assert e["db_abs"] <= gt * e["db_ref"] + t["db"] * noise, (name, e)
 
 
 @pytest.mark.parametrize("bm", [128, 256, 192, 512])

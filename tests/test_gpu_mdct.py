@@ -107,3 +107,46 @@ def test_edge_cases():
     # out_dtype gives the reference's float64 container
     m64 = MDCT4(n_fft=64, hop_length=32, win_length=64, window=kbdwin, device="cuda", out_dtype=torch.float64)
     assert m64(torch.zeros(2, 96)).dtype == torch.float64
+
+
+@pytest.mark.parametrize("n_fft", [1024, 2048])
+def test_register_resident_kernels_equal_generic_kernels(n_fft):
+    """hop = n_fft/2, win = n_fft at n_fft 1024 / 2048 runs the wave-per-frame kernels of csrc/mdct_fast.hip; every other
+    geometry the generic LDS kernels of csrc/mdct.hip.  Both must give the same numbers (and the same frame layout) on
+    ragged lengths, the `len(signal)` quirk, out_length crops, and through autograd."""
+    from pix2pixhdaudiosr_amd import _lib
+    from pix2pixhdaudiosr_amd.models.mdct import MDCT4, IMDCT4
+    from pix2pixhdaudiosr_amd.util.util import kbdwin
+    L = _lib.lib()
+    hop = n_fft // 2
+    gen = torch.Generator().manual_seed(n_fft)
+    w = kbdwin(n_fft)
+    for B, T in ((3, 9 * hop), (2, 17 * hop + 4 * 37), (5, 8 * hop - 8), (1, hop), (32, 7 * hop)):
+        x = torch.randn(B, T, generator=gen).cuda()
+        res = {}
+        for generic in (0, 1):
+            _lib.check(L.p2phd_set_option(b"mdct_generic", generic))
+            try:
+                mdct = MDCT4(n_fft=n_fft, hop_length=hop, win_length=n_fft, window=w, device="cuda")
+                xv = x.clone().requires_grad_(True)
+                S = mdct(xv)
+                cot = torch.randn(S.shape, generator=torch.Generator().manual_seed(1)).cuda()
+                (gx,) = torch.autograd.grad((S * cot).sum(), xv)
+                out = [S.detach(), gx]
+                for ol in (None, T, T - 4 * 25):
+                    imdct = IMDCT4(n_fft=n_fft, hop_length=hop, win_length=n_fft, window=w, device="cuda", out_length=ol)
+                    Sv = S.detach().clone().requires_grad_(True)
+                    y = imdct(Sv)
+                    ycot = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).cuda()
+                    (gS,) = torch.autograd.grad((y * ycot).sum(), Sv)
+                    out += [y.detach(), gS]
+                res[generic] = out
+            finally:
+                _lib.check(L.p2phd_set_option(b"mdct_generic", 0))
+        for a, b in zip(res[0], res[1]):
+            assert a.shape == b.shape
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, (n_fft, B, T)
+    # a length that is not a multiple of 4 is not eligible for the float4 kernels and must still work
+    x = torch.randn(2, 5 * hop + 3, generator=gen).cuda()
+    mdct = MDCT4(n_fft=n_fft, hop_length=hop, win_length=n_fft, window=w, device="cuda")
+    assert torch.isfinite(mdct(x)).all()
