@@ -171,10 +171,20 @@ def _compile(seq):
     return steps
 
 
-def _run(steps, x, residual_last=None):
+def _run(steps, x, residual_last=None, cuts=None, cut_after=()):
+    """Run fused steps in order.  `cuts` (a list) collects the output of every step whose index is in `cut_after`: the
+    points where the staged backward of the data-parallel step hands over (Pix2PixHDModel._phase_a)."""
     for j, s in enumerate(steps):
         x = s.run(x, residual_last if j == len(steps) - 1 else None)
+        if cuts is not None and j in cut_after:
+            cuts.append(x)
     return x
+
+
+def _step_params(step):
+    if isinstance(step, _ResStep):
+        return _step_params(step.a) + _step_params(step.b)
+    return [p for p in (step.conv.weight, step.conv.bias) if p is not None]
 
 
 class _HipNet(nn.Module):
@@ -280,8 +290,30 @@ class GlobalGenerator(_HipNet):
         layers += _c7(ngf, output_nc, None, nn.Tanh())
         self.model = nn.Sequential(*layers)
 
-    def forward_physical(self, x):
-        return _run(self._steps('model'), x)
+    def forward_physical(self, x, cuts=None, cut_after=()):
+        return _run(self._steps('model'), x, cuts=cuts, cut_after=cut_after)
+
+    def bucket_plan(self, n_buckets):
+        """Cut points for a backward in `n_buckets` stages of roughly equal parameter bytes (the gradient
+        all-reduce of a bucket starts when its last weight gradient is done).  Parameters are registered in execution
+        order, so the layers after a cut own a contiguous TAIL of the flat gradient buffer.
+        Returns (cut_after, first_param_index): step indices in execution order, and for every cut the index (into
+        list(self.parameters())) of the first parameter of the step that follows it."""
+        steps = self._steps('model')
+        counts = [sum(p.numel() for p in _step_params(s)) for s in steps]
+        total = sum(counts)
+        if n_buckets <= 1 or len(steps) < 2:
+            return [], []
+        cut_after, acc, want = [], 0, total / n_buckets
+        for j in range(len(steps) - 1, 0, -1):                # walk backwards: the backward's order
+            acc += counts[j]
+            if acc >= want and len(cut_after) < n_buckets - 1:
+                cut_after.append(j - 1)
+                acc = 0
+        cut_after = sorted(set(cut_after))
+        ids = [id(p) for p in self.parameters()]
+        first = [ids.index(id(_step_params(steps[j + 1])[0])) for j in cut_after]
+        return cut_after, first
 
     def forward(self, input):
         return _ops.FromPhysical.apply(self.forward_physical(self._to_phys(input)), self.output_nc)

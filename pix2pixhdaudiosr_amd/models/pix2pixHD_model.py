@@ -240,7 +240,14 @@ class Pix2PixHDModel(BaseModel):
         lr_spectro, lr_pha, hr_spectro, hr_pha, _, _, hr_norm_param, lr_norm_param = \
             self.encode_input(lr_audio, None, hr_audio, None, noise=noise)
 
-        sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro))
+        # cut points of the staged generator backward (data parallel: one gradient bucket per stage, see _g_stages)
+        _, cut_after, _ = self._bucket_plan()
+        self._cuts = [] if cut_after else None
+        if cut_after:
+            sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro), cuts=self._cuts,
+                                                 cut_after=set(cut_after))
+        else:
+            sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro))
         sr_result = _ops.FromPhysical.apply(sr_phys, self.opt.output_nc)
 
         if share_fake_pass:
@@ -296,18 +303,81 @@ class Pix2PixHDModel(BaseModel):
     # one full optimisation step (train.py:148-184) with the all-reduce of the G gradients overlapped
     # with the D backward pass; result-identical to calling backward/step in train.py's order
     # ------------------------------------------------------------------------------------------
-    def _phase_a(self, lr_audio, hr_audio, noise=None):
-        """Forward of G and D, all losses, zeroed gradient buffers, backward of the generator loss."""
+    def _bucket_plan(self):
+        """(n_buckets, cut_after, offsets): where the generator backward is cut into stages and the element offset in
+        optimizer_G's flat buffers at which each cut's later layers start.  `opt.grad_buckets` overrides the default
+        (4 with data parallelism, 1 without).  Needs optimizer_G to own all of netG's parameters in module order."""
+        if not self.isTrain:
+            return 1, [], []
+        optG = self.optimizer_G
+        n = int(_opt(self.opt, 'grad_buckets', 4 if optG.world_size > 1 else 1))
+        plan = getattr(self, '_bucket_plan_cache', None)
+        if plan is None or plan[0] != (n, id(optG)):
+            cut_after, offs = [], []
+            whole = len(optG._params) == len(list(self.netG.parameters()))
+            if n > 1 and whole and hasattr(self.netG, 'bucket_plan'):
+                cut_after, first = self.netG.bucket_plan(n)
+                offs = [optG.param_offset(i) for i in first]
+            plan = ((n, id(optG)), cut_after, offs)
+            self._bucket_plan_cache = plan
+        return plan[0][0], plan[1], plan[2]
+
+    def _phase_a_forward(self, lr_audio, hr_audio, noise=None):
+        """Forward of G and D, all losses, zeroed gradient buffers.  Returns the loss dict; the generator backward is
+        then run stage by stage with `_g_stages()`."""
         losses, _ = self._losses(lr_audio, hr_audio, noise, share_fake_pass=True)
         ld = dict(zip(self.loss_names, losses))
         self._loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
-        loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
+        self._loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
         self.optimizer_G.zero_grad()
         self.optimizer_D.zero_grad()
-        # G backward: only G parameters receive gradients (inputs= keeps autograd off the D leaves; D's convs skip their
-        # weight-gradient kernels in this pass).  The graph through D(fake) is kept for the D loss.
-        with _ops.backward_without_weight_grads(self.optimizer_D._params):
-            loss_G.backward(inputs=list(self.optimizer_G._params), retain_graph=True)
+        self.optimizer_G.bucket_log = []
+        self.optimizer_D.bucket_log = []
+        return ld
+
+    def _g_stages(self):
+        """The backward of the generator loss as a list of (run, (start, stop)) stages, last layers first.  Running a
+        stage computes the weight gradients of its layers straight into optimizer_G.flat_g[start:stop] (a contiguous
+        range: parameters are laid out in execution order), so the caller can start that range's all-reduce while the
+        next stage runs (bucketed exchange overlapped with the backward).  Only G parameters receive
+        gradients (D's convs skip their weight-gradient kernels in this pass); the graph through D(fake) is kept for
+        the D loss.  One stage = today's single backward."""
+        optG, optD = self.optimizer_G, self.optimizer_D
+        cuts, loss_G = self._cuts, self._loss_G
+        _, _, offs = self._bucket_plan()
+        total = optG._total
+        if not cuts:
+            def whole():
+                with _ops.backward_without_weight_grads(optD._params):
+                    loss_G.backward(inputs=list(optG._params), retain_graph=True)
+            return [(whole, (0, total))]
+        state = {}
+        stages = []
+
+        def head():
+            with _ops.backward_without_weight_grads(optD._params):
+                (state['g'],) = torch.autograd.grad(loss_G, [cuts[-1]], retain_graph=True)
+        stages.append((head, (offs[-1], total)))
+        for i in range(len(cuts) - 2, -1, -1):
+            def mid(i=i):
+                (state['g'],) = torch.autograd.grad(cuts[i + 1], [cuts[i]], grad_outputs=state['g'], retain_graph=True)
+            stages.append((mid, (offs[i], offs[i + 1])))
+        first_params = [p for p, o in zip(optG._params, optG._offs) if o < offs[0]]
+
+        def tail():
+            cuts[0].backward(gradient=state['g'], inputs=first_params, retain_graph=True)
+            state.clear()
+        stages.append((tail, (0, offs[0])))
+        return stages
+
+    def _phase_a(self, lr_audio, hr_audio, noise=None):
+        """Forward, losses and the whole generator backward, with each gradient bucket's all-reduce started as soon as
+        its stage is done (no-ops on one GPU)."""
+        ld = self._phase_a_forward(lr_audio, hr_audio, noise)
+        for run, (a, b) in self._g_stages():
+            run()
+            self.optimizer_G.reduce_range_async(a, b)
+        self._loss_G = None
         return ld
 
     def _phase_b(self):
@@ -318,8 +388,7 @@ class Pix2PixHDModel(BaseModel):
             loss_D.backward(inputs=list(self.optimizer_D._params))
 
     def train_step(self, lr_audio, hr_audio, noise=None):
-        ld = self._phase_a(lr_audio, hr_audio, noise)
-        self.optimizer_G.reduce_gradients_async()                   # overlaps the D backward
+        ld = self._phase_a(lr_audio, hr_audio, noise)              # G buckets are in flight: they overlap the D backward
         self._phase_b()
         self.optimizer_D.reduce_gradients_async()
         self.optimizer_G.step()
@@ -328,15 +397,16 @@ class Pix2PixHDModel(BaseModel):
 
     # ------------------------------------------------------------------------------------------
     # the same step captured once into HIP graphs and replayed: ~10^3 launches and the whole autograd walk cost no
-    # host time afterwards, so the step rate no longer depends on the host core that feeds the GPU.  Three graphs
-    # on one memory pool -- A: forward + G backward, B: D backward, C: both Adam updates -- so that with data
-    # parallelism the two RCCL all-reduces run BETWEEN replays, outside capture, the G one overlapping graph B.
+    # host time afterwards, so the step rate no longer depends on the host core that feeds the GPU.  Graphs on one
+    # memory pool -- A0: forward + first stage of the G backward, A1..: its further stages (one per gradient bucket),
+    # B: D backward, C: both Adam updates -- so that with data parallelism the RCCL all-reduces run BETWEEN replays,
+    # outside capture: bucket i's exchange beside stage i+1, the last G bucket and the rest beside graph B.
     # ------------------------------------------------------------------------------------------
     def train_step_graphed(self, lr_audio, hr_audio):
         """`train_step` through captured graphs.  Inputs are copied into static buffers; the returned loss tensors are
-        static outputs of graph A (valid until the next call).  Mask noise is drawn inside the graph."""
+        static outputs of graph A0 (valid until the next call).  Mask noise is drawn inside the graph."""
         st = getattr(self, '_graph_state', None)
-        key = (tuple(lr_audio.shape), tuple(hr_audio.shape), self.optimizer_G.world_size)
+        key = (tuple(lr_audio.shape), tuple(hr_audio.shape), self.optimizer_G.world_size, self._bucket_plan()[0])
         if st is None or st['key'] != key:
             dev = self.device
             st = {'key': key, 'lr': torch.empty(lr_audio.shape, dtype=torch.float32, device=dev),
@@ -352,29 +422,44 @@ class Pix2PixHDModel(BaseModel):
             if st['calls'] <= 2:                                   # eager steps first: workspaces, packed-weight buffers,
                 return self.train_step(st['lr'], st['hr'])          # library state all exist before capture
             torch.cuda.synchronize()
-            gA, gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             # back-to-back captures on one side stream and one pool, without the cache flush torch.cuda.graph()
             # does on entry (blocks the first capture freed must stay where its replay will write them)
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            gA, ranges = [], []
             with torch.cuda.stream(side):
-                gA.capture_begin()
-                st['out'] = self._phase_a(st['lr'], st['hr'])
-                gA.capture_end()
-                gB.capture_begin(pool=gA.pool())
+                g0 = torch.cuda.CUDAGraph()
+                g0.capture_begin()
+                st['out'] = self._phase_a_forward(st['lr'], st['hr'])
+                stages = self._g_stages()
+                for i, (run, rng) in enumerate(stages):
+                    if i > 0:
+                        g = torch.cuda.CUDAGraph()
+                        g.capture_begin(pool=g0.pool())
+                    else:
+                        g = g0
+                    run()
+                    g.capture_end()
+                    gA.append(g)
+                    ranges.append(rng)
+                self._loss_G = None
+                gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                gB.capture_begin(pool=g0.pool())
                 self._phase_b()
                 gB.capture_end()
-                gC.capture_begin(pool=gA.pool())
+                gC.capture_begin(pool=g0.pool())
                 optG.step_local()
                 optD.step_local()
                 gC.capture_end()
             torch.cuda.current_stream().wait_stream(side)
             optG.step_count -= 1                                   # capture records, it does not execute
             optD.step_count -= 1
-            st['graphs'] = (gA, gB, gC)
-        gA, gB, gC = st['graphs']
-        gA.replay()
-        optG.reduce_gradients_async()                               # no-ops on one GPU
+            st['graphs'] = (gA, ranges, gB, gC)
+        gA, ranges, gB, gC = st['graphs']
+        optG.bucket_log, optD.bucket_log = [], []
+        for g, (a, b) in zip(gA, ranges):
+            g.replay()
+            optG.reduce_range_async(a, b)                           # no-ops on one GPU
         gB.replay()
         optD.reduce_gradients_async()
         optG.wait_gradients()

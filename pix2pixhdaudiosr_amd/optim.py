@@ -47,6 +47,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.process_group = process_group
         self.world_size = 1
         self._pending = None
+        self.bucket_log = []
         _ops.bump_weight_epoch()
 
     def _install_grad_views(self):
@@ -68,17 +69,32 @@ class FlatAdam(torch.optim.Optimizer):
         self.world_size = int(world_size)
         self.process_group = process_group
 
-    def reduce_gradients_async(self):
-        """Start the gradient all-reduce (call right after backward); step() waits for it."""
-        if self.world_size > 1 and self._pending is None:
+    def param_offset(self, index):
+        """Element offset inside the flat buffers of parameter `index` (construction order)."""
+        return self._offs[index]
+
+    def reduce_range_async(self, start, stop):
+        """Start the summing all-reduce of flat_g[start:stop] (one bucket of a staged backward).  Buckets must not
+        overlap; the launches are recorded in `bucket_log` (tests assert order and coverage)."""
+        if self.world_size > 1 and stop > start:
             from .parallel_state import all_reduce_flat_async
+            if self._pending is None:
+                self._pending = []
+            self._pending.append(all_reduce_flat_async(self.flat_g[start:stop], self.process_group))
+        self.bucket_log.append((int(start), int(stop)))
+
+    def reduce_gradients_async(self):
+        """Start the gradient all-reduce of the whole buffer (call right after backward); step() waits for it."""
+        if self.world_size > 1 and self._pending is None:
             self._install_grad_views()
-            self._pending = all_reduce_flat_async(self.flat_g, self.process_group)
+            self.bucket_log = []
+            self.reduce_range_async(0, self._total)
 
     def wait_gradients(self):
-        """Make the current stream wait for the gradient all-reduce started by reduce_gradients_async()."""
+        """Make the current stream wait for every gradient all-reduce started since the last wait."""
         if self._pending is not None:
-            self._pending.wait()
+            for h in self._pending:
+                h.wait()
             self._pending = None
 
     @torch.no_grad()

@@ -42,6 +42,8 @@ def main():
             first = {"G": model.optimizer_G.flat_p.cpu().clone(), "D": model.optimizer_D.flat_p.cpu().clone()}
     torch.cuda.synchronize()
     torch.save({"G": model.optimizer_G.flat_p.cpu(), "D": model.optimizer_D.flat_p.cpu(), "losses": losses, "first": first,
+                "buckets_G": list(model.optimizer_G.bucket_log), "buckets_D": list(model.optimizer_D.bucket_log),
+                "total_G": model.optimizer_G._total, "total_D": model.optimizer_D._total,
                 "steps": model.optimizer_G.steps_taken(), "graphed": getattr(model, "_graph_state", None) is not None
                 and model._graph_state["graphs"] is not None},
                os.path.join(out_dir, f"{mode}_rank{rank}.pt"))

@@ -28,6 +28,13 @@ def test_two_ranks_one_gpu(tmp_path, mode):
     assert r0["steps"] == r1["steps"] == 5
     assert r0["graphed"] == (mode == "graphed")
     assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["D"], r1["D"])      # replicas stay bit-identical
+    # bucketed exchange: the generator gradients left in 4 all-reduces, last layers first (the order the backward
+    # produces them), contiguous, non-overlapping, covering the whole flat buffer; D in one
+    for r in (r0, r1):
+        bk = r["buckets_G"]
+        assert len(bk) == 4 and bk[0][1] == r["total_G"] and bk[-1][0] == 0, bk
+        assert all(a < b for a, b in bk) and all(bk[i][0] == bk[i + 1][1] for i in range(3)), bk
+        assert r["buckets_D"] == [(0, r["total_D"])]
     assert torch.isfinite(r0["G"]).all() and torch.isfinite(r0["D"]).all()
     for step_losses in r0["losses"]:
         assert all(abs(v) < 1e3 for v in step_losses.values())

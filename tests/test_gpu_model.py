@@ -335,3 +335,34 @@ def test_amp_call_sequence_of_train_py(golden_model):
         strong = gr.abs() > 1e-2 * gr.abs().max()
         assert float((oa.flat_p - ob.flat_p).abs()[strong].max()) <= 2e-6
     assert all(torch.isfinite(p).all() for p in a.parameters())
+
+
+def test_staged_backward_equals_single_backward(golden_model):
+    """grad_buckets = 4 cuts the generator backward into four stages (what the data-parallel step overlaps with its
+    all-reduces): same kernels in the same order as the single backward, so gradients agree to the order of the float
+    atomics, on one GPU with no communication at all; graphed replay of the stages included."""
+    g = golden_model
+    lr, hr = torch.from_numpy(g["lr"]).cuda(), torch.from_numpy(g["hr"]).cuda()
+    one, four = _model(g, mask=False), _model(g, mask=False, grad_buckets=4)
+    n, cut_after, offs = four._bucket_plan()
+    assert n == 4 and len(cut_after) == 3 and offs == sorted(offs) and 0 < offs[0] and offs[-1] < four.optimizer_G._total
+    assert one._bucket_plan()[1] == []
+    la = one.train_step(lr, hr)
+    lb = four.train_step(lr, hr)
+    bk = four.optimizer_G.bucket_log
+    assert [b for _, b in bk][0] == four.optimizer_G._total and bk[-1][0] == 0 and len(bk) == 4
+    assert all(bk[i][0] == bk[i + 1][1] for i in range(3))
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= 1e-5 * max(1.0, abs(float(la[k]))), k
+    for oa, ob in ((one.optimizer_G, four.optimizer_G), (one.optimizer_D, four.optimizer_D)):
+        assert float((oa.flat_g - ob.flat_g).norm() / oa.flat_g.norm()) < 1e-4
+    # the staged capture: A0 .. A3 | B | C
+    for _ in range(4):
+        four.train_step_graphed(lr, hr)
+    gA, ranges, _, _ = four._graph_state['graphs']
+    assert len(gA) == 4 and ranges == bk
+    _reset(one, g); _reset(four, g)
+    one.train_step(lr, hr)
+    four.train_step_graphed(lr, hr)
+    assert float((one.optimizer_G.flat_g - four.optimizer_G.flat_g).norm() / one.optimizer_G.flat_g.norm()) < 1e-4
+    assert four.optimizer_G.bucket_log == bk

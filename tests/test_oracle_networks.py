@@ -94,3 +94,28 @@ def test_param_counts_and_keys(golden_networks):
     for name, spec in specs.items():
         assert N.param_count(spec) == counts[name], name
         assert list(spec.keys()) == [str(k) for k in g[f"keys_{name}"]], name
+
+
+def test_three_scale_discriminator():
+    """oracle vs the reference's own num_D = 3 run (tests/golden/networks_d3.npz, tools/gen_golden.py --only networks_d3)."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "networks_d3.npz"))
+    tag = "D3"
+    p, keys = _params(g, tag)
+    spec = N.multiscale_discriminator_spec(4, 8, 3, 3, True)
+    assert list(spec.keys()) == keys
+    x = torch.from_numpy(g[f"{tag}_x"]).requires_grad_(True)
+    res = N.multiscale_discriminator_forward(p, x, 8, 3, 3, True)
+    assert [len(s) for s in res] == list(g[f"{tag}_nfeat"])
+    flat = [f for s in res for f in s]
+    tot = 0
+    for i, f in enumerate(flat):
+        assert f.shape == g[f"{tag}_f{i}"].shape
+        assert rel_err(f.detach().numpy(), g[f"{tag}_f{i}"]) < TOL
+        tot = tot + (f * torch.from_numpy(g[f"{tag}_c{i}"])).sum()
+    grads = torch.autograd.grad(tot, [x] + list(p.values()))
+    assert rel_err(grads[0].numpy(), g[f"{tag}_gx"]) < 1e-4
+    nb = noise_bias_keys(keys)
+    for k, gr in zip(keys, grads[1:]):
+        assert_grad_close(f"{tag}:{k}", gr.numpy(), g[f"{tag}_g_{k}"], noise_biases=nb)

@@ -249,6 +249,34 @@ def gen_networks(out):
     print("networks.npz", len(d), "arrays;", counts)
 
 
+def gen_networks_d3(out):
+    """Three-scale MultiscaleDiscriminator (BASELINE configs[4]: num_D 3; reference models/networks.py:292-331): features of
+    every stage of every scale, input and parameter gradients.  Own file so that networks.npz keeps its random draws."""
+    import models.networks as RN
+    import contextlib, io
+    d = {}
+    torch.manual_seed(4321)
+    with contextlib.redirect_stdout(io.StringIO()):
+        D = RN.define_D(4, 8, 3, "instance", False, 3, True, [])
+    x = torch.rand(2, 4, 64, 32).requires_grad_(True)
+    res = D(x)
+    flat = [f for s in res for f in s]
+    cots = [torch.randn_like(f) for f in flat]
+    tot = sum((f * c).sum() for f, c in zip(flat, cots))
+    grads = torch.autograd.grad(tot, [x] + list(D.parameters()))
+    tag = "D3"
+    d[f"{tag}_x"] = _np(x); d[f"{tag}_gx"] = _np(grads[0])
+    for i, (f, c) in enumerate(zip(flat, cots)):
+        d[f"{tag}_f{i}"] = _np(f); d[f"{tag}_c{i}"] = _np(c)
+    d[f"{tag}_nfeat"] = np.array([len(s) for s in res])
+    for (k, v), gr in zip(D.named_parameters(), grads[1:]):
+        d[f"{tag}_p_{k}"] = _np(v); d[f"{tag}_g_{k}"] = _np(gr)
+    d[f"{tag}_keys"] = np.array(list(D.state_dict().keys()))
+    d["torch_version"] = np.array(torch.__version__)
+    np.savez_compressed(os.path.join(out, "networks_d3.npz"), **d)
+    print("networks_d3.npz", len(d), "arrays; feature shapes", [tuple(f.shape) for f in flat])
+
+
 def gen_model(out):
     """Pix2PixHDModel on CPU with the reference's own MDCT4 swapped in for MDCT2 (README.md:133 invites it)."""
     import contextlib, io
@@ -440,6 +468,8 @@ def main():
         gen_mdct(a.out)
     if "networks" in todo:
         gen_networks(a.out)
+    if "networks_d3" in todo:
+        gen_networks_d3(a.out)
     if "model" in todo:
         gen_model(a.out)
     if "evaltail" in todo:
