@@ -93,6 +93,8 @@ def _check_arena(ctx, device):
 # measurement hook: `match(spec, N, H, W) -> bool` selects conv layers whose forward launch is bracketed by HIP events on
 # the launch stream (eager steps only); bench.py times the dominant kernel inside a real step this way
 _KERNEL_PROBE = {"match": None, "events": []}
+# debugging hook: when a list, every conv block's backward appends (spec, g, dy, gx) clones (tools only)
+_BWD_TRACE = [None]
 
 
 # parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
@@ -146,6 +148,51 @@ def cpitch(c):
     return (c + 7) & ~7
 
 
+# Guard-band mode (tests / tools only; GPU AddressSanitizer is not available on this pool): every buffer this module
+# hands to a kernel as an OUTPUT is carved out of a larger allocation whose 4 KiB margins are filled with a sentinel;
+# `check_guards()` verifies that no kernel wrote outside its tensor.
+_GUARD = {"on": False, "live": []}
+_GUARD_BYTES = 4096
+_SENTINEL = 0xA5
+
+
+def empty(shape, dtype, device):
+    if not _GUARD["on"]:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    pad = (nbytes + 255) & ~255
+    raw = torch.full((pad + 2 * _GUARD_BYTES,), _SENTINEL, dtype=torch.uint8, device=device)
+    t = raw[_GUARD_BYTES:_GUARD_BYTES + nbytes].view(dtype).view(shape)
+    _GUARD["live"].append((raw, nbytes, tuple(int(d) for d in shape), str(dtype)))
+    return t
+
+
+def empty_like(t):
+    return empty(tuple(t.shape), t.dtype, t.device)
+
+
+def check_guards(clear=True):
+    """Raise if any guard band was written; returns the number of buffers checked."""
+    torch.cuda.synchronize()
+    bad = []
+    for raw, nbytes, shape, dt in _GUARD["live"]:
+        lo = raw[:_GUARD_BYTES]
+        hi = raw[_GUARD_BYTES + nbytes:]
+        for name, band in (("below", lo), ("above", hi)):
+            hit = (band != _SENTINEL).nonzero()
+            if hit.numel():
+                bad.append((shape, dt, name, int(hit.numel()), int(hit[0]), int(hit[-1])))
+    n = len(_GUARD["live"])
+    if clear:
+        _GUARD["live"] = []
+    if bad:
+        raise _lib.P2PHDError(f"out-of-bounds device writes next to {len(bad)} buffer(s): {bad[:6]}")
+    return n
+
+
 def dt_code(dtype):
     try:
         return _DT[dtype]
@@ -158,6 +205,8 @@ _WS = {}
 
 def workspace(nbytes, device):
     """Grow-only scratch buffer per device; kernels on one stream run in order, so consecutive ops share it."""
+    if _GUARD["on"]:
+        return empty((max(int(nbytes), 256),), torch.uint8, device)
     key = str(device)
     t = _WS.get(key)
     if t is None or t.numel() < nbytes:
@@ -184,7 +233,7 @@ def to_physical(x_nchw, dtype, out=None, ch_off=0):
     x = x_nchw.contiguous().float()
     N, Cc, H, W = x.shape
     if out is None:
-        out = torch.zeros((N, H, W, cpitch(ch_off + Cc)), dtype=dtype, device=x.device)
+        out = empty((N, H, W, cpitch(ch_off + Cc)), dtype, x.device).zero_()
     check(lib().p2phd_nchw_to_nhwc(dt_code(out.dtype), ptr(x), ptr(out), N, Cc, H * W, out.shape[-1], ch_off, stream_ptr()),
           "nchw_to_nhwc")
     return out
@@ -192,7 +241,7 @@ def to_physical(x_nchw, dtype, out=None, ch_off=0):
 
 def from_physical(x_phys, channels, ch_off=0):
     N, H, W, Cp = x_phys.shape
-    out = torch.empty((N, channels, H, W), dtype=torch.float32, device=x_phys.device)
+    out = empty((N, channels, H, W), torch.float32, x_phys.device)
     check(lib().p2phd_nhwc_to_nchw(dt_code(x_phys.dtype), ptr(x_phys), ptr(out), N, channels, H * W, Cp, ch_off, stream_ptr()),
           "nhwc_to_nchw")
     return out
@@ -206,7 +255,7 @@ class ToPhysical(torch.autograd.Function):
         ctx.chans = [int(x.shape[1]) for x in xs]
         total = sum(ctx.chans)
         N, _, H, W = xs[0].shape
-        out = torch.zeros((N, H, W, cpitch(total)), dtype=dtype, device=xs[0].device)
+        out = empty((N, H, W, cpitch(total)), dtype, xs[0].device).zero_()
         off = 0
         for x in xs:
             to_physical(x, dtype, out=out, ch_off=off)
@@ -233,7 +282,7 @@ class FromPhysical(torch.autograd.Function):
     def backward(ctx, g):
         dtype, Cp = ctx.meta
         N, Cc, H, W = g.shape
-        out = torch.zeros((N, H, W, Cp), dtype=dtype, device=g.device)
+        out = empty((N, H, W, Cp), dtype, g.device).zero_()
         to_physical(g, dtype, out=out)
         return out, None
 
@@ -270,7 +319,7 @@ class ConvSpec:
         if hit is not None and hit[0] == stamp:
             return hit[1]
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
-        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
         w = weight.detach()
         if w.dtype != torch.float32 or not w.is_contiguous():
             w = w.float().contiguous()
@@ -292,7 +341,7 @@ class ConvBlockFn(torch.autograd.Function):
         Cp_out = cpitch(spec.cout)
         wp = spec.packed(weight, 0, d)
         b = None if bias is None else bias.detach().float().contiguous()
-        y = torch.empty((N, Ho, Wo, Cp_out), dtype=x.dtype, device=x.device)
+        y = empty((N, Ho, Wo, Cp_out), x.dtype, x.device)
         stats = zeros((N, Cp_out, 2), x.device) if spec.norm else None
         fused_act = ACT_NONE if spec.norm else spec.act
         wsb = L.p2phd_conv_fwd_workspace_bytes(C.byref(d))
@@ -309,7 +358,7 @@ class ConvBlockFn(torch.autograd.Function):
             _KERNEL_PROBE["events"].append((e0, e1))
         if spec.norm:
             res = None if residual is None else phys(residual, "residual")
-            out = torch.empty_like(y)
+            out = empty_like(y)
             check(L.p2phd_instnorm_act_fwd(d.dtype, ptr(y), ptr(stats), ptr(res), ptr(out), N, Ho * Wo, spec.cout, IN_EPS,
                                            spec.act, stream_ptr()), "instnorm_act_fwd")
         else:
@@ -342,18 +391,18 @@ class ConvBlockFn(torch.autograd.Function):
         direct = need_w and _direct_grad(weight) and (not ctx.has_bias or _direct_grad(ctx.bias))
         gb = None
         if need_w and ctx.has_bias:
-            gb = ctx.bias.grad if direct else torch.empty((spec.cout,), dtype=torch.float32, device=y.device)
+            gb = ctx.bias.grad if direct else empty((spec.cout,), torch.float32, y.device)
         gb_done = False
         if spec.norm:
-            dy = torch.empty_like(y)
-            bstats = torch.empty((N, Cp_out, 2), dtype=torch.float32, device=y.device)
+            dy = empty_like(y)
+            bstats = empty((N, Cp_out, 2), torch.float32, y.device)
             # the bias gradient (column sums of dy) rides on the apply pass
             bwd = L.p2phd_instnorm_act_bwd_acc if direct else L.p2phd_instnorm_act_bwd
             check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
                       stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
         elif spec.act != ACT_NONE:
-            dy = torch.empty_like(y)
+            dy = empty_like(y)
             if gb is not None:                                     # bias gradient rides on the activation-backward pass
                 check(L.p2phd_act_bwd_db(d.dtype, ptr(g), ptr(y), ptr(dy), N * Ho * Wo, spec.cout, spec.act, ptr(gb),
                                          1 if direct else 0, stream_ptr()), "act_bwd_db")
@@ -364,7 +413,7 @@ class ConvBlockFn(torch.autograd.Function):
             dy = g
         gx = gw = None
         if need_w:
-            gw = weight.grad if direct else torch.empty(weight.shape, dtype=torch.float32, device=y.device)
+            gw = weight.grad if direct else empty(tuple(weight.shape), torch.float32, y.device)
             ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device)
             wgrad = L.p2phd_conv_wgrad_acc if direct else L.p2phd_conv_wgrad
             check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
@@ -372,7 +421,7 @@ class ConvBlockFn(torch.autograd.Function):
                 gw = gb = None
         if ctx.needs_input_grad[0] and id(spec) not in _BWD_SKIP_DGRAD_SPECS:
             wp = spec.packed(weight, 1, d)
-            gx = torch.empty_like(x)
+            gx = empty_like(x)
             wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))
             ws = workspace(wsb, y.device) if wsb else None
             # first conv of a residual block: the skip gradient parked by the block's second conv is added inside the
@@ -381,6 +430,8 @@ class ConvBlockFn(torch.autograd.Function):
             if ctx.link is not None and ctx.link.role_of(ctx) == "a":
                 addend = ctx.link.take()
             check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
+        if _BWD_TRACE[0] is not None:
+            _BWD_TRACE[0].append((spec, g.detach().clone(), dy.detach().clone(), None if gx is None else gx.detach().clone()))
         gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
         if gres is not None and ctx.link is not None and ctx.link.park(gres, ctx):
             gres = None
@@ -426,7 +477,7 @@ class AvgPoolFn(torch.autograd.Function):
         x = phys(x, "avgpool input")
         N, H, W, Cp = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-        y = torch.empty((N, Ho, Wo, Cp), dtype=x.dtype, device=x.device)
+        y = empty((N, Ho, Wo, Cp), x.dtype, x.device)
         check(lib().p2phd_avgpool3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), N, H, W, channels, stream_ptr()), "avgpool_fwd")
         ctx.meta = (N, H, W, Cp, channels)
         return y
@@ -435,7 +486,7 @@ class AvgPoolFn(torch.autograd.Function):
     def backward(ctx, g):
         N, H, W, Cp, channels = ctx.meta
         g = g.contiguous()
-        dx = torch.empty((N, H, W, Cp), dtype=g.dtype, device=g.device)
+        dx = empty((N, H, W, Cp), g.dtype, g.device)
         check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
         return dx, None
 
@@ -466,10 +517,13 @@ class LossFn(torch.autograd.Function):
     def backward(ctx, g):
         kind, target, coeff, channels, P = ctx.meta
         a, b = ctx.a, ctx.b
-        da = torch.empty_like(a)
+        da = empty_like(a)
         g = g.contiguous().float()
         check(lib().p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(a), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
                                    stream_ptr()), "loss_bwd")
+        if _BWD_TRACE[0] is not None:
+            _BWD_TRACE[0].append((("loss", kind, tuple(a.shape), coeff), g.detach().clone(), da.detach().clone(),
+                                  None if b is None else b.detach().clone()))
         return da, None, None, None, None, None
 
 

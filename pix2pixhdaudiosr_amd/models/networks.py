@@ -304,11 +304,13 @@ class GlobalGenerator(_HipNet):
         total = sum(counts)
         if n_buckets <= 1 or len(steps) < 2:
             return [], []
-        cut_after, acc, want = [], 0, total / n_buckets
+        cut_after, acc, remaining, left = [], 0, total, n_buckets
         for j in range(len(steps) - 1, 0, -1):                # walk backwards: the backward's order
             acc += counts[j]
-            if acc >= want and len(cut_after) < n_buckets - 1:
+            if left > 1 and acc >= remaining / left:          # this bucket holds its share of what is still unassigned
                 cut_after.append(j - 1)
+                remaining -= acc
+                left -= 1
                 acc = 0
         cut_after = sorted(set(cut_after))
         ids = [id(p) for p in self.parameters()]
