@@ -55,8 +55,9 @@ def time_trunk_conv(batch, iters=20):
     y = torch.empty_like(x)
     stats = torch.zeros(batch, 768, 2, device="cuda")
     L = _ops.lib()
+    ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
-                                               None, _ops.stream_ptr()))
+                                               _ops.ptr(ws), _ops.stream_ptr()))
     sec = time_graphed(call, iters)
     flops = 2.0 * batch * 32 * 16 * 768 * 768 * 9
     return sec, flops

@@ -127,10 +127,12 @@ int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
 size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which);
 int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w, void* packed, void* stream);
 
-/* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], zeroed by the caller) the per-(n,channel)
- * sum and sum of squares of conv(x)+bias are accumulated into it (what InstanceNorm2d needs, networks.py:22). */
-/* scratch of the forward launch: the folded tensor of <= 4-channel layers and, for outputs of more than 16384 pixels per
- * sample, the per-tile statistics table that a small kernel reduces into `stats`; 0 for every other layer */
+/* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], overwritten; act must be NONE) it receives, per
+ * (n, channel), the MEAN and the SUM OF SQUARED DEVIATIONS from it of conv(x)+bias over the sample's plane -- what
+ * InstanceNorm2d needs (networks.py:22).  Every wave of the conv epilogue stores the partial of its rows about its own
+ * mean (plain stores into a table in `workspace`), a small kernel merges them in a fixed order (Chan et al.): no float
+ * atomics (bit-reproducible) and no E[x^2] - E[x]^2 cancellation. */
+/* scratch of the forward launch: the folded tensor of <= 4-channel layers and the per-wave statistics partials */
 size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_fwd, const float* bias, int act,
                    void* y, float* stats, void* workspace, void* stream);
@@ -156,7 +158,7 @@ int p2phd_conv_wgrad_acc(const p2phd_conv_desc* c, const void* x, const void* dy
 
 /* out = act((y - mean) * rstd) + residual: InstanceNorm2d(affine=False, eps) (networks.py:22) + ReLU /
  * LeakyReLU(0.2) / none, + the ResnetBlock skip (networks.py:252) or the LocalEnhancer sum (:180) when
- * residual != NULL.  stats = the float [N][Cp][2] (sum, sum of squares) p2phd_conv_fwd accumulated. */
+ * residual != NULL.  stats = the float [N][Cp][2] (mean, sum of squared deviations) p2phd_conv_fwd wrote. */
 int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
                            int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dy from g = dL/d(out) through act and InstanceNorm; bstats: float [N][Cp][2] scratch (zeroed inside).

@@ -386,35 +386,51 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int col = wn * (NR * 32) + j * 32 + lr;
-      int k = n0 + col;
+      int k = n0 + col, kcls = 0;
       if (cls_cp > 0) {                                        // merged sub-pixel classes share bias / statistics of channel k
         if (k >= n_extent) k = Kout;
-        else k -= ((k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp)) * cls_cp;
+        else { kcls = (k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp); k -= kcls * cls_cp; }
       }
       const float bv = (bias != nullptr && k < Kout) ? bias[k] : 0.f;
-      float s1 = 0.f, s2 = 0.f;
+      float s1 = 0.f;
 #pragma unroll
       for (int i = 0; i < MR; ++i) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           float v = acc[i][j][e] + bv;
-          if (p_base + row < p_end) { s1 += v; s2 += v * v; }
+          if (p_base + row < p_end) s1 += v;
           if constexpr (ACT == P2PHD_ACT_TANH) v = tanhf(v);
           else v = v > 0.f ? v : neg_slope * v;                // none / ReLU / LeakyReLU(0.2) as one select
           *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
         }
       }
       if (stats != nullptr) {
+        // InstanceNorm partial of this wave's MR*32 rows: (sum, sum of squared deviations from the wave's OWN mean),
+        // stored plainly in the wave's slot of a [N][slots][classes][Cp][2] table that a small kernel merges with Chan's
+        // update.  No float atomics (bit-reproducible), and no E[x^2] - E[x]^2 cancellation: a dB spectrogram puts
+        // |mean| / sigma up to 25 in front of the first InstanceNorm, which costs that formula 3 digits in fp32.
         s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
+        const int first = p_base + wm * (MR * 32);
+        const int cnt = min(max(p_end - first, 0), MR * 32);
+        const float mean_w = cnt > 0 ? s1 / (float)cnt : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < MR; ++i) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const float dlt = acc[i][j][e] + bv - mean_w;
+            if (p_base + row < p_end) m2 += dlt * dlt;
+          }
+        }
+        m2 += __shfl_xor(m2, 32);
         if (lh == 0 && k < Kout) {
-          // per-sample sums, or (layers with hundreds of tiles per sample) this tile's own slot of a partial table:
-          // no contended float atomics, no extra pass over the output
-          float* sp = stats_slots > 0 ? stats + 2 * (((size_t)n * stats_slots + (p_base >> 7)) * Cp_out + k)
-                                      : stats + 2 * ((size_t)n * Cp_out + k);
-          atomicAdd(sp, s1);
-          atomicAdd(sp + 1, s2);
+          const int slot = first / (MR * 32);
+          const int ncls = cls_cp > 0 ? 4 : 1;
+          float* sp = stats + 2 * ((((size_t)n * stats_slots + slot) * ncls + kcls) * Cp_out + k);
+          sp[0] = s1;
+          sp[1] = m2;
         }
       }
     }
@@ -1196,8 +1212,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 // host side
 // ------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
-int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
-                     float* stats, hipStream_t st) {
+int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const float* bias, const void* addend, void* out,
+                     float* stats, hipStream_t st, int* slot_rows) {
+  GDesc d = d_in;
+  // InstanceNorm partials: one slot per wave row block (MR * 32 rows) of a sample, see the epilogue
+  d.stats_slots = (d.Hg * d.Wg + MR * 32 - 1) / (MR * 32);
+  if (slot_rows) *slot_rows = MR * 32;
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int CT = BM * (BN * (int)sizeof(T) + 16);
   const int tab = ((d.nth * d.ntw * BM * 4 + 15) & ~15) + BM * 8;        // gather table + row table
@@ -1215,7 +1235,7 @@ int launch_gconv_cfg(const GDesc& d, const void* in, const void* wp, const float
 
 template <typename T>
 int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, const void* addend, void* out,
-                   float* stats, hipStream_t st) {
+                   float* stats, hipStream_t st, int* slot_rows) {
   // N tile: the 128-wide tile has the best MFMA density (64x64 per wave) and reads the gathered A operand once;
   // narrower tiles only for layers that would leave most of it empty
   if (d.n_extent == 0) d.n_extent = d.Cp_out;
@@ -1247,30 +1267,30 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
   if (force == 192 && sizeof(T) == 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
-    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
+    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if (huge && force == 0 && k % 192 == 0) {
     const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
     const double c256 = std::ceil(wg256 / 256.0) * 256.0 * 256.0, c192 = std::ceil(wg192 / 256.0) * 256.0 * 192.0 / 0.95;
     if (c192 < c256 && 2 * 448 * kRowBytes + tabb <= kLds)
-      return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
+      return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
   // where 128-wide tiles would gather the A operand once more and pad the last tile
   if (!huge && force == 0 && sizeof(T) == 2 && enough_px && !short_k && k % 192 == 0 && k <= 384 &&
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
-    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st);
-  if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st);
+    return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if (big && bn == 128) {
-    if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st);
-    return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
+    if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+    return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   if (big && bn == 64) {
-    if (fits3) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st);
-    return launch_gconv_cfg<T, 256, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st);
+    if (fits3) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+    return launch_gconv_cfg<T, 256, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
-  if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st);
-  if (bn == 64) return launch_gconv_cfg<T, 128, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st);
-  return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st);
+  if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  if (bn == 64) return launch_gconv_cfg<T, 128, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
 }
 
 }  // namespace
@@ -1278,7 +1298,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
 namespace p2phd {
 
 int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
-                 void* out, float* stats, hipStream_t st) {
+                 void* out, float* stats, hipStream_t st, int* slot_rows) {
   if (d_in.N == 0 || d_in.Hg * d_in.Wg == 0) return P2PHD_OK;
   GDesc d = d_in;
   {
@@ -1291,8 +1311,8 @@ int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, c
   }
   P2PHD_REQUIRE(d.Cp_in % 8 == 0 && d.Cp_out % 8 == 0, "gconv: channel pitch must be a multiple of 8");
   P2PHD_REQUIRE((long)d.N * d.Hin * d.Win < (1l << 31) && (long)d.N * d.Hout * d.Wout < (1l << 31), "gconv: too many pixels");
-  if (dtype == P2PHD_BF16) return launch_gconv_t<bf16_t>(d, in, wp, bias, addend, out, stats, st);
-  if (dtype == P2PHD_F32) return launch_gconv_t<float>(d, in, wp, bias, addend, out, stats, st);
+  if (dtype == P2PHD_BF16) return launch_gconv_t<bf16_t>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  if (dtype == P2PHD_F32) return launch_gconv_t<float>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   set_error("gconv: unsupported dtype %d", dtype);
   return P2PHD_EUNSUPPORTED;
 }

@@ -212,9 +212,6 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
   }
 }
 
-// more than ~128 epilogue adds per (n, channel) address: 128-row tiles x 2 waves along M
-bool separate_stats(int Ho, int Wo) { return ((long)Ho * Wo + 127) / 128 * 2 > 256; }
-
 size_t padded_dx_bytes(const p2phd_conv_desc* c) {
   if (c->pad_mode != 1) return 0;
   return align256((size_t)c->N * (c->H + 2 * c->pad) * (c->W + 2 * c->pad) * cpitch(c->C) * elem_size(c->dtype));
@@ -263,14 +260,11 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   return P2PHD_OK;
 }
 
-// per-tile InstanceNorm sums of a many-tile layer: [N][slots][Cp][2] floats behind the layer's other scratch
-int stat_slots(const std::vector<Plan>& plans) {
-  int slots = 0;
-  for (const auto& p : plans) slots = std::max(slots, (p.d.Hg * p.d.Wg + 127) / 128);
-  return slots;
-}
-size_t stat_table_bytes(const p2phd_conv_desc* c, const std::vector<Plan>& plans) {
-  return align256((size_t)c->N * stat_slots(plans) * cpitch(c->K) * 2 * sizeof(float));
+// per-wave InstanceNorm partials of the conv epilogues: [N][slots][classes][Cp][2] floats behind the layer's other scratch
+size_t stat_table_bytes(const std::vector<Plan>& plans) {
+  size_t n = 0;
+  for (const auto& p : plans) n = std::max(n, stat_table_floats(p.d));
+  return align256(n * sizeof(float));
 }
 
 extern "C" size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c) {
@@ -278,10 +272,11 @@ extern "C" size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c) {
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   const int fold = fold_mode(c);
-  if (fold == FOLD_OUT) return folded_dy_bytes(c, Ho, Wo);      // Y has the shape of the folded dy
+  if (fold == FOLD_OUT)                                          // Y has the shape of the folded dy; statistics: plane pass
+    return folded_dy_bytes(c, Ho, Wo) + align256(plane_stats_scratch_floats(c->N, (long)Ho * Wo, c->K) * sizeof(float));
   std::vector<Plan> plans; WMap m;
   make_plans(c, 0, plans, &m);
-  const size_t table = separate_stats(Ho, Wo) ? stat_table_bytes(c, plans) : 0;
+  const size_t table = stat_table_bytes(plans);
   if (fold == FOLD_IN) return folded_x_bytes(c, Wo) + table;
   return table;
 }
@@ -290,6 +285,7 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
                               void* y, float* stats, void* workspace, void* stream) {
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(act >= P2PHD_ACT_NONE && act <= P2PHD_ACT_RELU, "conv_fwd: bad activation %d", act);
+  P2PHD_REQUIRE(stats == nullptr || act == P2PHD_ACT_NONE, "conv_fwd: InstanceNorm statistics are taken of the pre-activation output");
   if (c->N == 0) return P2PHD_OK;
   P2PHD_REQUIRE(x && wp && y, "conv_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -298,44 +294,37 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   const int fold = fold_mode(c);
-  P2PHD_REQUIRE(fold == FOLD_NONE || workspace, "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch");
+  P2PHD_REQUIRE((fold == FOLD_NONE && stats == nullptr) || workspace,
+                "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch (W-fold image / statistics partials)");
   if (fold == FOLD_OUT) {
     Plan& p = plans[0];
     if (int rc = launch_gconv(p.d, c->dtype, x, wp, nullptr, nullptr, workspace, nullptr, st)) return rc;
-    return launch_hsum(c->dtype, workspace, bias, y, stats, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, act, st);
+    if (int rc = launch_hsum(c->dtype, workspace, bias, y, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, act, st)) return rc;
+    if (stats == nullptr) return P2PHD_OK;
+    float* scratch = reinterpret_cast<float*>(static_cast<char*>(workspace) + folded_dy_bytes(c, Ho, Wo));
+    return launch_plane_stats(c->dtype, y, stats, scratch, c->N, (long)Ho * Wo, c->K, st);
   }
+  const void* src = x;
+  float* table = static_cast<float*>(workspace);
   if (fold == FOLD_IN) {
     if (int rc = launch_expand_in(c->dtype, x, workspace, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
-    Plan& p = plans[0];
-    p.d.act = act;
-    const bool sep = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
-    if (!sep) return launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, stats, st);
-    float* table = reinterpret_cast<float*>(static_cast<char*>(workspace) + folded_x_bytes(c, Wo));
-    const int slots = stat_slots(plans);
-    (void)hipMemsetAsync(table, 0, stat_table_bytes(c, plans), st);
-    p.d.stats_slots = slots;
-    if (int rc = launch_gconv(p.d, c->dtype, workspace, wp, bias, nullptr, y, table, st)) return rc;
-    return launch_tile_stats_reduce(table, stats, c->N, slots, cpitch(c->K), st);
+    src = workspace;
+    table = reinterpret_cast<float*>(static_cast<char*>(workspace) + folded_x_bytes(c, Wo));
   }
-  // InstanceNorm sums: in the conv epilogue (float atomics, one per wave and channel) unless a sample spans so many
-  // M tiles that thousands of adds would pile onto each (n, channel) address; then a stand-alone pass over y is cheaper
-  const bool sep_stats = stats != nullptr && act == P2PHD_ACT_NONE && separate_stats(Ho, Wo);
-  float* table = nullptr;
-  int slots = 0;
-  if (sep_stats) {
-    P2PHD_REQUIRE(workspace, "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch (per-tile statistics)");
-    table = static_cast<float*>(workspace);
-    slots = stat_slots(plans);
-    (void)hipMemsetAsync(table, 0, stat_table_bytes(c, plans), st);
-  }
+  // InstanceNorm statistics: every wave of the conv epilogue stores the partial of its rows (plain stores), one merge
+  // launch turns them into (mean, sum of squared deviations) per (sample, channel)
+  P2PHD_REQUIRE(stats == nullptr || plans.size() == 1, "conv_fwd: statistics need a single-launch plan");
+  int slot_rows = 0;
   for (auto& p : plans) {
     p.d.act = act;
-    p.d.stats_slots = slots;
     const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
-    if (int rc = launch_gconv(p.d, c->dtype, x, w, bias, nullptr, y, sep_stats ? table : stats, st)) return rc;
+    if (int rc = launch_gconv(p.d, c->dtype, src, w, bias, nullptr, y, stats ? table : nullptr, st, &slot_rows)) return rc;
   }
-  if (sep_stats) return launch_tile_stats_reduce(table, stats, c->N, slots, cpitch(c->K), st);
-  return P2PHD_OK;
+  if (stats == nullptr) return P2PHD_OK;
+  const GDesc& d = plans[0].d;
+  const long npix = (long)d.Hg * d.Wg;
+  return launch_stats_merge(table, stats, c->N, (int)((npix + slot_rows - 1) / slot_rows), d.cls_cp > 0 ? 4 : 1, cpitch(c->K), c->K,
+                            npix, slot_rows, st);
 }
 
 extern "C" size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c) {

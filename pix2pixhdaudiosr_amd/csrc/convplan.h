@@ -19,7 +19,7 @@ struct GDesc {
                                               //      class (pi,pj) = (col / cls_cp) writes output pixel (2*ho+pi, 2*wo+pj)
   int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
-  int stats_slots;                            // > 0: `stats` is a [N][stats_slots][Cp_out][2] table of per-tile sums (slot = first row / 128)
+  int stats_slots;                            // slots per sample of the statistics table (set by the launcher)
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -44,8 +44,18 @@ extern int g_opt_wgrad_tm;
 inline int cpitch(int c) { return (c + 7) & ~7; }
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// `stats` (optional): [N][slots][classes][Cp_out][2] table of per-wave InstanceNorm partials (sum, squared deviations
+// from the wave's mean), slots = ceil(Hg * Wg / *slot_rows), classes = 4 for merged sub-pixel launches else 1; merge
+// with launch_stats_merge.  stat_table_floats() bounds its size for any tile configuration.
 int launch_gconv(const GDesc& d, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
-                 void* out, float* stats, hipStream_t st);
+                 void* out, float* stats, hipStream_t st, int* slot_rows = nullptr);
+inline size_t stat_table_floats(const GDesc& d) {
+  return (size_t)d.N * ((d.Hg * d.Wg + 31) / 32) * (d.cls_cp > 0 ? 4 : 1) * d.Cp_out * 2;
+}
+// stats[n][c] = (mean, sum of squared deviations) over the sample's plane, merged from `slots` partials per class in a
+// fixed order (Chan et al.); slot s holds rows [s * slot_rows, (s+1) * slot_rows) of the npix rows of a sample.
+int launch_stats_merge(const float* table, float* stats, int N, int slots, int ncls, int Cp, int C, long npix, int slot_rows,
+                       hipStream_t st);
 size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad);
 int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int Cp_r, int M_rows, int M_rows_pad,
                  const void* gat, float* dwp, float* dw, int accumulate, hipStream_t st);
@@ -56,12 +66,13 @@ int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx
                         hipStream_t st);
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st);
 
-int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st);
-int launch_tile_stats_reduce(const float* partial, float* stats, int N, int slots, int Cp, hipStream_t st);
+// stand-alone statistics of a [N][HW][Cp] tensor (W-folded layers): `scratch` = plane_stats_scratch_floats() floats
+size_t plane_stats_scratch_floats(int N, long HW, int C);
+int launch_plane_stats(int dtype, const void* y, float* stats, float* scratch, int N, long HW, int C, hipStream_t st);
 int launch_expand_in(int dtype, const void* x, void* xe, int N, int H, int W, int Wo, int C, int S, int pad, int pad_mode,
                      hipStream_t st);
 int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo, int Wy, int K, int S, hipStream_t st);
-int launch_hsum(int dtype, const void* Y, const float* bias, void* y, float* stats, int N, int H, int Wo, int Wy, int K, int S,
+int launch_hsum(int dtype, const void* Y, const float* bias, void* y, int N, int H, int Wo, int Wy, int K, int S,
                 int act, hipStream_t st);
 
 }  // namespace p2phd

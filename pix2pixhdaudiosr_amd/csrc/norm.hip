@@ -43,11 +43,10 @@ struct ChanConsts {
     const float4* s4 = reinterpret_cast<const float4*>(stats + 2 * ((size_t)n * Cp + pc * EPP));
 #pragma unroll
     for (int k = 0; k < EPP; k += 2) {
-      const float4 v = s4[k >> 1];                               // (sum, sumsq) of two channels
-      const float m0 = v.x * inv, m1 = v.z * inv;
-      mean[k] = m0; mean[k + 1] = m1;
-      rstd[k] = (pc * EPP + k < C) ? rsqrtf(fmaxf(v.y * inv - m0 * m0, 0.f) + eps) : 0.f;
-      rstd[k + 1] = (pc * EPP + k + 1 < C) ? rsqrtf(fmaxf(v.w * inv - m1 * m1, 0.f) + eps) : 0.f;
+      const float4 v = s4[k >> 1];                               // (mean, sum of squared deviations) of two channels
+      mean[k] = v.x; mean[k + 1] = v.z;
+      rstd[k] = (pc * EPP + k < C) ? rsqrtf(fmaxf(v.y * inv, 0.f) + eps) : 0.f;
+      rstd[k + 1] = (pc * EPP + k + 1 < C) ? rsqrtf(fmaxf(v.w * inv, 0.f) + eps) : 0.f;
     }
   }
 };
@@ -321,46 +320,29 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
   }
 }
 
-// ---- per-(n,c) sum and sum of squares of a plane (InstanceNorm statistics as a stand-alone pass) ----
-// Used instead of the conv-epilogue atomics for layers with many M tiles per sample (48/96-channel layers at
-// 512x256 / 256x128): thousands of float atomics on one address are far slower than one more read of the tensor.
+// ---- stand-alone InstanceNorm statistics of a plane (layers whose output does not come out of gconv_kernel) ----
+// Workgroup (chunk, n) owns kPlaneChunk consecutive pixels of sample n: per channel it writes (sum, squared deviations
+// from the chunk's own mean) into slot `chunk` of the partial table; launch_stats_merge combines the chunks.
+constexpr int kPlaneChunk = 256;
 template <typename T>
-__global__ __launch_bounds__(256) void plane_stats_kernel(const T* __restrict__ y, float* __restrict__ stats, long HW, int C, int Cp) {
-  constexpr int EPP = Elem<T>::EPP;
-  constexpr int UN = 4;
-  extern __shared__ float s_acc[];                              // [Cp][2]
-  for (int c = threadIdx.x; c < 2 * Cp; c += 256) s_acc[c] = 0.f;
-  __syncthreads();
-  const int n = blockIdx.y;
-  const int cpr = Cp / EPP;
-  const long total = HW * cpr;
-  const size_t base = (size_t)n * HW * Cp;
-  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
-  float a1[EPP], a2[EPP];
-#pragma unroll
-  for (int k = 0; k < EPP; ++k) a1[k] = a2[k] = 0.f;
-  const long stride = (long)gridDim.x * 256;
-  const long last = total - 1;
-  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < total; e0 += stride * UN) {
-    uint4 yv[UN];
-#pragma unroll
-    for (int u = 0; u < UN; ++u)                                // unconditional, clamped (see in_act_fwd_kernel)
-      yv[u] = *reinterpret_cast<const uint4*>(y + base + (size_t)min(e0 + u * stride, last) * EPP);
-#pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const float live = e0 + u * stride < total ? 1.f : 0.f;
-      const T* yy = reinterpret_cast<const T*>(&yv[u]);
-#pragma unroll
-      for (int k = 0; k < EPP; ++k) { const float v = to_f(yy[k]) * live; a1[k] += v; a2[k] += v * v; }
+__global__ __launch_bounds__(256) void plane_stats_kernel(const T* __restrict__ y, float* __restrict__ table, long HW, int C, int Cp,
+                                                          int slots) {
+  extern __shared__ float s_sum[];                              // [Cp] sums, then [Cp] means
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const long p0 = (long)chunk * kPlaneChunk;
+  const int cnt = (int)min((long)kPlaneChunk, HW - p0);
+  const T* base = y + ((size_t)n * HW + p0) * Cp;
+  for (int c = threadIdx.x; c < Cp; c += 256) {                 // channel-per-thread: rows are contiguous, Cp small here
+    float a = 0.f;
+    for (int p = 0; p < cnt; ++p) a += to_f(base[(size_t)p * Cp + c]);
+    const float mean = a / (float)cnt;
+    float m2 = 0.f;
+    for (int p = 0; p < cnt; ++p) { const float d = to_f(base[(size_t)p * Cp + c]) - mean; m2 += d * d; }
+    if (c < C) {
+      float* sp = table + 2 * (((size_t)n * slots + chunk) * Cp + c);
+      sp[0] = a; sp[1] = m2;
     }
   }
-#pragma unroll
-  for (int k = 0; k < EPP; ++k) {
-    atomicAdd(&s_acc[2 * (pc * EPP + k)], a1[k]);
-    atomicAdd(&s_acc[2 * (pc * EPP + k) + 1], a2[k]);
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += 256) atomicAdd(&stats[2 * (size_t)n * Cp + c], s_acc[c]);
 }
 
 // ---- activation backward from the saved OUTPUT (conv layers whose activation is fused, no norm) ----
@@ -567,45 +549,72 @@ int stationary_grid(long HW, int cpr, int N) {
 }  // namespace
 
 namespace {
-// stats[n][c][2] += sum over the tile slots of partial[n][slot][c][2] (written by the conv epilogue in stats_slots mode)
-__global__ __launch_bounds__(256) void tile_stats_reduce_kernel(const float* __restrict__ partial, float* __restrict__ stats,
-                                                                int slots, int Cp2, int per) {
-  const int n = blockIdx.y;
-  const int s0 = blockIdx.x * per, s1 = min(slots, s0 + per);
-  for (int c = threadIdx.x; c < Cp2; c += 256) {
-    const float* src = partial + ((size_t)n * slots + s0) * Cp2 + c;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int s = s0;
-    for (; s + 4 <= s1; s += 4) {
-      a0 += src[0]; a1 += src[(size_t)Cp2]; a2 += src[(size_t)2 * Cp2]; a3 += src[(size_t)3 * Cp2];
-      src += (size_t)4 * Cp2;
+// One wavefront per (sample, channel): lane l folds slots l, l + 64, ... with Chan's pairwise update in a fixed order,
+// then the 64 lane results are folded by a fixed shuffle tree -- the result does not depend on timing.
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+  const float n = na + nb;
+  if (nb > 0.f) {
+    const float d = mb - ma, f = nb / n;
+    ma += d * f;
+    qa += qb + d * d * na * f;
+    na = n;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restrict__ table, float* __restrict__ stats, int slots,
+                                                          int ncls, int Cp, int C, long npix, int slot_rows) {
+  const int n = blockIdx.y, lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;                                           // wave-uniform
+  float cn = 0.f, cm = 0.f, cq = 0.f;
+  for (int s = lane; s < slots; s += 64) {
+    const float cnt = (float)min((long)slot_rows, max(npix - (long)s * slot_rows, 0l));
+    for (int k = 0; k < ncls; ++k) {
+      const float* sp = table + 2 * ((((size_t)n * slots + s) * ncls + k) * Cp + c);
+      if (cnt > 0.f) chan_merge(cn, cm, cq, cnt, sp[0] / cnt, sp[1]);
     }
-    for (; s < s1; ++s) { a0 += *src; src += Cp2; }
-    atomicAdd(&stats[(size_t)n * Cp2 + c], (a0 + a1) + (a2 + a3));
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float on = __shfl_xor(cn, o), om = __shfl_xor(cm, o), oq = __shfl_xor(cq, o);
+    // both partners must compute the SAME merged value: order the pair by lane so the update is symmetric
+    float an = (lane & o) ? on : cn, am = (lane & o) ? om : cm, aq = (lane & o) ? oq : cq;
+    const float bn = (lane & o) ? cn : on, bm = (lane & o) ? cm : om, bq = (lane & o) ? cq : oq;
+    chan_merge(an, am, aq, bn, bm, bq);
+    cn = an; cm = am; cq = aq;
+  }
+  if (lane == 0) {
+    float* o = stats + 2 * ((size_t)n * Cp + c);
+    o[0] = cm; o[1] = cq;
   }
 }
 }  // namespace
 
 namespace p2phd {
-int launch_tile_stats_reduce(const float* partial, float* stats, int N, int slots, int Cp, hipStream_t st) {
-  if (N == 0 || slots == 0) return P2PHD_OK;
-  const int chunks = std::max(1, std::min(slots / 16, 64));
-  const int per = (slots + chunks - 1) / chunks;
-  hipLaunchKernelGGL(tile_stats_reduce_kernel, dim3((unsigned)((slots + per - 1) / per), (unsigned)N), dim3(256), 0, st, partial, stats,
-                     slots, 2 * Cp, per);
-  return check_launch("tile_stats_reduce");
+int launch_stats_merge(const float* table, float* stats, int N, int slots, int ncls, int Cp, int C, long npix, int slot_rows,
+                       hipStream_t st) {
+  if (N == 0 || slots == 0 || C == 0) return P2PHD_OK;
+  hipLaunchKernelGGL(stats_merge_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)N), dim3(256), 0, st, table, stats, slots, ncls, Cp, C,
+                     npix, slot_rows);
+  return check_launch("stats_merge");
 }
 
-int launch_plane_stats(int dtype, const void* y, float* stats, int N, long HW, int C, hipStream_t st) {
+size_t plane_stats_scratch_floats(int N, long HW, int C) {
+  const int Cp = (C + 7) & ~7;
+  return (size_t)N * ((HW + kPlaneChunk - 1) / kPlaneChunk) * Cp * 2;
+}
+
+int launch_plane_stats(int dtype, const void* y, float* stats, float* scratch, int N, long HW, int C, hipStream_t st) {
   const int Cp = (C + 7) & ~7;
   if (N == 0 || HW == 0) return P2PHD_OK;
-  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
-  dim3 grid(stationary_grid(HW, Cp / epp, N), N);
+  const int slots = (int)((HW + kPlaneChunk - 1) / kPlaneChunk);
+  dim3 grid((unsigned)slots, (unsigned)N);
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(plane_stats_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)y, stats, HW, C, Cp);
+    hipLaunchKernelGGL(plane_stats_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, scratch, HW, C, Cp, slots);
   else
-    hipLaunchKernelGGL(plane_stats_kernel<float>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const float*)y, stats, HW, C, Cp);
-  return check_launch("plane_stats");
+    hipLaunchKernelGGL(plane_stats_kernel<float>, grid, dim3(256), 0, st, (const float*)y, scratch, HW, C, Cp, slots);
+  if (int rc = check_launch("plane_stats")) return rc;
+  return launch_stats_merge(scratch, stats, N, slots, 1, Cp, C, HW, kPlaneChunk, st);
 }
 }  // namespace p2phd
 

@@ -83,15 +83,13 @@ __global__ __launch_bounds__(256) void expand_dy_kernel(const T* __restrict__ dy
   }
 }
 
-// y[n,h,w,k] = act(bias_k + sum_tw Y[n,h,w+tw,(tw*K+k)]); optional InstanceNorm partial sums
+// y[n,h,w,k] = act(bias_k + sum_tw Y[n,h,w+tw,(tw*K+k)])
 template <typename T>
 __global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, const float* __restrict__ bias, T* __restrict__ y,
-                                                   float* __restrict__ stats, int H, int Wo, int Wy, int K, int Kp, int S,
-                                                   int Cep, int act) {
+                                                   int H, int Wo, int Wy, int K, int Kp, int S, int Cep, int act) {
   // grid: (blocks over H*Wo pixels, N); thread -> one output pixel, all K (<= 4) channels
   const int n = blockIdx.y;
   const long HW = (long)H * Wo;
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
     const int w = (int)(p % Wo);
     const long h = p / Wo;
@@ -100,11 +98,10 @@ __global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, cons
 #pragma unroll
     for (int k = 0; k < 8; ++k) outv[k] = from_f<T>(0.f);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                                // K <= 4; literal k keeps s1 / s2 / outv in registers
+    for (int k = 0; k < 4; ++k) {                                // K <= 4; literal k keeps outv in registers
       if (k < K) {
         float a = bias != nullptr ? bias[k] : 0.f;
         for (int tw = 0; tw < S; ++tw) a += to_f(row[(size_t)tw * Cep + tw * K + k]);
-        s1[k] += a; s2[k] += a * a;
         if (act == P2PHD_ACT_TANH) a = tanhf(a);
         else if (act == P2PHD_ACT_LRELU) a = a > 0.f ? a : 0.2f * a;
         else if (act == P2PHD_ACT_RELU) a = a > 0.f ? a : 0.f;
@@ -114,20 +111,6 @@ __global__ __launch_bounds__(256) void hsum_kernel(const T* __restrict__ Y, cons
     T* o = y + ((size_t)n * HW + p) * Kp;
     if (sizeof(T) == 2) *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(outv);
     else { *reinterpret_cast<uint4*>(o) = *reinterpret_cast<uint4*>(outv); *reinterpret_cast<uint4*>(o + 4) = *reinterpret_cast<uint4*>(outv + 4); }
-  }
-  if (stats != nullptr) {
-    __shared__ float red[4][8];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = s1[k], b = s2[k];
-      for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-      if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][2 * k] = a; red[threadIdx.x >> 6][2 * k + 1] = b; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * K) {
-      const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-      atomicAdd(&stats[2 * ((size_t)n * Kp + (threadIdx.x >> 1)) + (threadIdx.x & 1)], t);
-    }
   }
 }
 
@@ -162,15 +145,15 @@ int launch_expand_dy(int dtype, const void* dy, void* dye, int N, int Ho, int Wo
   return check_launch("expand_dy");
 }
 
-int launch_hsum(int dtype, const void* Y, const float* bias, void* y, float* stats, int N, int H, int Wo, int Wy, int K, int S,
+int launch_hsum(int dtype, const void* Y, const float* bias, void* y, int N, int H, int Wo, int Wy, int K, int S,
                 int act, hipStream_t st) {
   P2PHD_REQUIRE(K <= 4, "hsum: at most 4 output channels");
   const int Kp = cpitch(K), Cep = cpitch(S * K);
   dim3 grid(grid_for((long)H * Wo, 1024), N);
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(hsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)Y, bias, (bf16_t*)y, stats, H, Wo, Wy, K, Kp, S, Cep, act);
+    hipLaunchKernelGGL(hsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)Y, bias, (bf16_t*)y, H, Wo, Wy, K, Kp, S, Cep, act);
   else
-    hipLaunchKernelGGL(hsum_kernel<float>, grid, dim3(256), 0, st, (const float*)Y, bias, (float*)y, stats, H, Wo, Wy, K, Kp, S, Cep, act);
+    hipLaunchKernelGGL(hsum_kernel<float>, grid, dim3(256), 0, st, (const float*)Y, bias, (float*)y, H, Wo, Wy, K, Kp, S, Cep, act);
   return check_launch("hsum");
 }
 

@@ -294,7 +294,8 @@ def test_device_state_adam_and_accumulating_entry_points():
     assert rel_err(dbb.cpu().numpy(), 2 * want[..., :40].sum((0, 1, 2)).cpu().numpy()) < 1e-5
     # --- instnorm_act_bwd_acc: same dy as the overwriting entry point, db added on top of what was there
     y = torch.randn(N, Ho, Wo, _ops.cpitch(40), device="cuda"); y[..., 40:] = 0
-    stats = torch.stack([y.sum((1, 2)), (y * y).sum((1, 2))], dim=-1).contiguous()
+    mean = y.mean((1, 2))
+    stats = torch.stack([mean, ((y - mean[:, None, None]) ** 2).sum((1, 2))], dim=-1).contiguous()   # (mean, M2) per (n, c)
     bst = torch.empty(N, _ops.cpitch(40), 2, device="cuda")
     dy1 = torch.empty_like(y); dy2 = torch.empty_like(y)
     db1 = torch.empty(40, device="cuda"); db2 = torch.full((40,), 3.0, device="cuda")
