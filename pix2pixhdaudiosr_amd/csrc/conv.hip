@@ -425,7 +425,7 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
           }
         }
         m2 += __shfl_xor(m2, 32);
-        if (lh == 0 && k < Kout) {
+        if (lh == 0 && k < Kout && cnt > 0) {                  // waves past the sample's last row own no slot
           const int slot = first / (MR * 32);
           const int ncls = cls_cp > 0 ? 4 : 1;
           float* sp = stats + 2 * ((((size_t)n * stats_slots + slot) * ncls + kcls) * Cp_out + k);
