@@ -1,0 +1,258 @@
+// Dedicated kernels for the 7x7 reflect-padded convolutions at the two ends of the generator (models/networks.py:190
+// Conv2d(2, ngf, 7) behind ReflectionPad2d(3); :207 Conv2d(ngf, 2, 7) + Tanh), bf16, full-resolution planes.
+//
+// These layers have 39 GFLOP of arithmetic per launch at B = 32 and move 0.47 GB: they are HBM-bound by a factor of
+// three even on padded MFMA tiles.  Run through the generic gather-GEMM (W-fold + 128x64 tiles) they were bound by the
+// gather path instead -- every output pixel re-gathered 7 x 32 bytes of a materialised 16-channel image -- at 0.8 TB/s.
+// Here a workgroup owns an 8 x 128 pixel tile of one sample:
+//   c7_in_fwd  (2 -> C_out):  the 15 x 136 input halo is read ONCE into LDS, compacted to its two channels (4 bytes
+//     per pixel, reflection applied while filling).  GEMM view per wave: A = weights [16 channels x K], B = patches
+//     [K x 16 pixels] with K ordered (dw, dh, c) = 8 x 8 x 2 (taps 7 and beyond carry zero weights), so a lane's B
+//     fragment of v_mfma_f32_16x16x32_bf16 is four aligned 4-byte LDS reads (rows dh0..dh0+3 of one pixel) and the A
+//     fragments -- the whole weight matrix -- stay in registers for the life of the wave.  The C tile comes out
+//     [channel][pixel]; it is staged through LDS and leaves as whole 1 KiB runs of NHWC rows.
+//   InstanceNorm statistics: every lane keeps shifted sums of its channels over the tile, merged across lanes with
+//     Chan's update once per wave, stored as this wave's slot of the same partial table the generic conv uses.
+#include "convplan.h"
+
+namespace {
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int TH = 8, TW = 128;            // output tile
+constexpr int LROWS = TH + 7;              // input rows held (3 above, 3 below, 1 for the zero-weight tap row 7)
+constexpr int LPITCH = 140;                // dwords per LDS input row: >= TW + 8, and 4 * LPITCH % 32 == 16 (bank spread)
+// bytes per pixel in the C staging image: NB * 32 of channels + padding that keeps rows 16-byte aligned and spreads the
+// 8-byte writes of 16 pixel lanes over the banks (pitch in dwords = 12, 20, 28, 44: 2-way at worst)
+constexpr int srow_bytes(int nb) { return nb == 4 ? 176 : nb * 32 + 16; }
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+// Weights in fragment order: wf[((half * NB + nb) * 4 + s) * 64 + lane] = 8 bf16:
+//   A[row = l & 15][k = 32 s + 8 (l >> 4) + j],  k = dw * 16 + dh * 2 + c,  value w[16 (half * NB + nb) + row][c][dh][dw]
+__global__ void c7_pack_in_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, int K, int nblocks) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nblocks * 4 * 64) return;
+  const int lane = idx & 63, s = (idx >> 6) & 3, blk = idx >> 8;
+  const int ch = 16 * blk + (lane & 15), g = lane >> 4;
+  bf16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int dw = 2 * s + (g >> 1), dh = 4 * (g & 1) + (j >> 1), c = j & 1;
+    const bool ok = ch < K && dh < 7 && dw < 7;
+    v[j] = (bf16_t)(ok ? w[((ch * 2 + c) * 7 + dh) * 7 + dw] : 0.f);
+  }
+  *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
+}
+
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+  const float n = na + nb;
+  const float d = mb - ma, f = nb / n;
+  ma += d * f;
+  qa += qb + d * d * na * f;
+  na = n;
+}
+
+// x [N,H,W,8] bf16 (channels 0,1 used) -> y [N,H,W,Cp] bf16, Cp = K (multiple of 16); grid (tiles, N, channel halves)
+template <int NB>
+__global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                        const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                        float* __restrict__ table, int H, int W, int Cp, int slots) {
+  __shared__ unsigned s_in[LROWS * LPITCH];
+  __shared__ __attribute__((aligned(16))) float s_bias[NB * 16];
+  constexpr int SROW = srow_bytes(NB);
+  __shared__ __attribute__((aligned(16))) unsigned char s_out[4][64 * SROW];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_w = W / TW;
+  const int th = blockIdx.x / tiles_w, tw = blockIdx.x - th * tiles_w;
+  const int n = blockIdx.y, half = blockIdx.z;
+  const int h0 = th * TH, w0 = tw * TW;
+  const int ch0 = half * NB * 16;
+
+  // weights of this channel half: NB x 4 fragments, resident for the whole tile
+  bf16x8 wa[NB][4];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+      wa[nb][s] = *reinterpret_cast<const bf16x8*>(wf + ((size_t)((half * NB + nb) * 4 + s) * 64 + lane) * 8);
+
+  // input halo, compacted to (c0, c1) per pixel, reflection folded into the fill
+  const unsigned* xin = reinterpret_cast<const unsigned*>(x) + (size_t)n * H * W * 4;      // 4 dwords per pixel
+  {
+    // all loads first (unconditional, clamped), then the LDS writes: a load inside the loop body with its own wait
+    // costs one memory round trip per iteration
+    constexpr int NE = LROWS * (TW + 8), NIT = (NE + 255) / 256;
+    unsigned v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = min(tid + 256 * it, NE - 1);
+      const int r = e / (TW + 8), c = e - r * (TW + 8);
+      const int hi = reflect_idx(h0 + r - 3, H), wi = reflect_idx(w0 + c - 3, W);
+      v[it] = xin[((size_t)hi * W + wi) * 4];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int e = tid + 256 * it;
+      const int r = e / (TW + 8), c = e - r * (TW + 8);
+      if (e < NE) s_in[r * LPITCH + c] = v[it];
+    }
+  }
+  if (tid < NB * 16) s_bias[tid] = bias != nullptr ? bias[ch0 + tid] : 0.f;
+  __syncthreads();
+
+  const int p = lane & 15, g = lane >> 4;
+  // B fragment of k-step s for the 16-pixel block at column c16: rows (dh0 .. dh0+3) of pixel c16 + p + dw,
+  // dw = 2 s + (g >> 1), dh0 = 4 (g & 1); element (row - 3) is the tap offset, the image starts 3 pixels left / above
+  const int lane_off = (4 * (g & 1)) * LPITCH + p + (g >> 1);
+
+  // shifted InstanceNorm sums of this lane's channels over the pixels it sees (16 per group)
+  float sh[NB][4], s1[NB][4], s2[NB][4];
+  bool first = true;
+
+  unsigned char* stage = s_out[wave];
+  // 16 groups of 64 pixels per tile (8 rows x 2), four per wave
+#pragma unroll 1
+  for (int q = 0; q < 4; ++q) {
+    const int grp = wave * 4 + q;
+    const int row = grp >> 1, col0 = (grp & 1) * 64;
+    f32x4 acc[4][NB];
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[mb][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // 16 (block, k-step) pairs; the fragment of pair i + 1 is read while the three MFMAs of pair i run
+    const unsigned* gbase = s_in + row * LPITCH + col0 + lane_off;
+    unsigned f[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[0][i] = gbase[i * LPITCH];
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int mb = st >> 2, s = st & 3;
+      if (st + 1 < 16) {
+        const int mb1 = (st + 1) >> 2, s1n = (st + 1) & 3;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[(st + 1) & 1][i] = gbase[16 * mb1 + i * LPITCH + 2 * s1n];
+      }
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(f[st & 1]);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][s], bfr, acc[mb][nb], 0, 0, 0);
+    }
+    // epilogue of the group: bias, statistics, bf16, stage [pixel][channel]
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const float4 b4 = *reinterpret_cast<const float4*>(s_bias + 16 * nb + 4 * g);
+        float v[4] = {acc[mb][nb][0] + b4.x, acc[mb][nb][1] + b4.y, acc[mb][nb][2] + b4.z, acc[mb][nb][3] + b4.w};
+        if (first && mb == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { sh[nb][r] = v[r]; s1[nb][r] = 0.f; s2[nb][r] = 0.f; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float d = v[r] - sh[nb][r]; s1[nb][r] += d; s2[nb][r] += d * d; }
+        bf16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+        *reinterpret_cast<uint2*>(stage + (16 * mb + p) * SROW + (16 * nb + 4 * g) * 2) = *reinterpret_cast<const uint2*>(o);
+      }
+    }
+    first = false;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // 64 pixels x (NB * 32) bytes leave as consecutive 16-byte pieces of consecutive NHWC rows
+    constexpr int CPP = NB * 2;                                  // 16-byte pieces per pixel (of this channel half)
+    bf16_t* orow = y + (((size_t)n * H + h0 + row) * W + w0 + col0) * Cp + ch0;
+#pragma unroll
+    for (int it = 0; it < CPP; ++it) {
+      const int piece = lane + 64 * it;
+      const int px = piece / CPP, pc = piece - px * CPP;
+      const uint4 v = *reinterpret_cast<const uint4*>(stage + px * SROW + pc * 16);
+      *reinterpret_cast<uint4*>(orow + (size_t)px * Cp + pc * 8) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+
+  if (table != nullptr) {
+    // per lane: 16 values per channel about the shift sh -> (n, mean, M2); Chan merge across the 16 pixel lanes
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        // equal counts at every level of the tree (16, 32, 64, 128 values a side): Chan's update is then symmetric in
+        // its two arguments -- mean = (a + b) / 2, M2 = qa + qb + (b - a)^2 n / 2 -- so both partners of a shuffle
+        // compute the same numbers with no ordering logic and no division
+        float cm = sh[nb][r] + s1[nb][r] * (1.f / 16.f);
+        float cq = s2[nb][r] - s1[nb][r] * s1[nb][r] * (1.f / 16.f);
+        float half_n = 8.f;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const float om = __shfl_xor(cm, o), oq = __shfl_xor(cq, o);
+          const float d = om - cm;
+          cq = (cq + oq) + d * d * half_n;
+          cm = 0.5f * (cm + om);
+          half_n *= 2.f;
+        }
+        const float cn = 256.f;
+        if (p == 0) {
+          const int c = ch0 + 16 * nb + 4 * g + r;
+          float* sp = table + 2 * (((size_t)n * slots + (size_t)blockIdx.x * 4 + wave) * Cp + c);
+          sp[0] = cm * cn;                                       // the table holds (sum, squared deviations) per slot
+          sp[1] = cq;
+        }
+      }
+  }
+}
+
+}  // namespace
+
+namespace p2phd {
+
+bool c7_in_ok(const p2phd_conv_desc* c) {
+  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->C == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+         c->pad == 3 && c->pad_mode == 1 && c->K % 16 == 0 && c->K >= 16 && c->K <= 128 && (c->K <= 64 || c->K % 32 == 0) &&
+         c->H % TH == 0 && c->W % TW == 0 && c->H > 3 && c->W > 3;
+}
+
+size_t c7_in_packed_elems(const p2phd_conv_desc* c) { return (size_t)(c->K / 16) * 4 * 64 * 8; }
+
+int c7_in_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st) {
+  const int nblocks = c->K / 16;
+  const int total = nblocks * 4 * 64;
+  hipLaunchKernelGGL(c7_pack_in_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, c->K, nblocks);
+  return check_launch("c7_pack");
+}
+
+int c7_in_slots(const p2phd_conv_desc* c) { return (c->H / TH) * (c->W / TW) * 4; }
+
+// y = conv7x7(reflect_pad3(x)) + bias; `table` (optional): [N][slots][Cp][2] statistics partials, 256 pixels per slot
+int c7_in_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, void* y, float* table, hipStream_t st) {
+  const int halves = c->K > 64 ? 2 : 1;
+  const int nb = c->K / 16 / halves;
+  dim3 grid((unsigned)((c->H / TH) * (c->W / TW)), (unsigned)c->N, (unsigned)halves);
+  const int slots = c7_in_slots(c);
+#define P2PHD_C7(NBV) hipLaunchKernelGGL(c7_in_fwd_kernel<NBV>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, bias, \
+                                         (bf16_t*)y, table, c->H, c->W, cpitch(c->K), slots)
+  switch (nb) {
+    case 1: P2PHD_C7(1); break;
+    case 2: P2PHD_C7(2); break;
+    case 3: P2PHD_C7(3); break;
+    case 4: P2PHD_C7(4); break;
+    default: set_error("c7_in_fwd: unsupported channel count %d", c->K); return P2PHD_EUNSUPPORTED;
+  }
+#undef P2PHD_C7
+  return check_launch("c7_in_fwd");
+}
+
+}  // namespace p2phd

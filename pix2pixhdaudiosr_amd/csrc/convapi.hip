@@ -46,6 +46,15 @@ int check_desc(const p2phd_conv_desc* c) {
   return P2PHD_OK;
 }
 
+// shape test only (what the packed buffer must hold); whether a call takes the fast kernel also depends on the option
+bool c7_fast_shape(const p2phd_conv_desc* c) {
+  const int keep = g_opt_c7_generic;
+  g_opt_c7_generic = 0;
+  const bool ok = c7_in_ok(c);
+  g_opt_c7_generic = keep;
+  return ok;
+}
+
 int fold_mode(const p2phd_conv_desc* c) {
   if (c->transposed || c->stride != 1) return FOLD_NONE;
   if (c->K <= 4 && c->S * c->K <= 32) return FOLD_OUT;
@@ -239,6 +248,7 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   make_plans(c, which, plans, &m);
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+  if (which == 0 && c7_fast_shape(c)) n += c7_in_packed_elems(c);           // fragment-ordered copy for c7.hip, behind the W-fold pack
   return n * elem_size(c->dtype);
 }
 
@@ -256,6 +266,11 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
       if (int rc = launch_pack_merged(p.d, c->dtype, w, dst, p.rows_pad, m.rows, m.inner, c->R, c->S, pad_eff, m.s_row, m.s_inner,
                                       (hipStream_t)stream)) return rc;
     } else if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
+  }
+  if (which == 0 && c7_fast_shape(c)) {
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    return c7_in_pack(c, w, static_cast<char*>(packed) + n * elem_size(c->dtype), (hipStream_t)stream);
   }
   return P2PHD_OK;
 }
@@ -306,6 +321,15 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
   }
   const void* src = x;
   float* table = static_cast<float*>(workspace);
+  if (fold == FOLD_IN && act == P2PHD_ACT_NONE && c7_in_ok(c)) {
+    // dedicated 2-channel 7x7 kernel (c7.hip): halo once through LDS, weights in registers, whole-row stores
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    const void* wf = static_cast<const char*>(wp) + n * elem_size(c->dtype);
+    if (int rc = c7_in_fwd(c, x, wf, bias, y, stats ? table : nullptr, st)) return rc;
+    if (stats == nullptr) return P2PHD_OK;
+    return launch_stats_merge(table, stats, c->N, c7_in_slots(c), 1, cpitch(c->K), c->K, (long)Ho * Wo, 256, st);
+  }
   if (fold == FOLD_IN) {
     if (int rc = launch_expand_in(c->dtype, x, workspace, c->N, c->H, c->W, Wo, c->C, c->S, c->pad, c->pad_mode, st)) return rc;
     src = workspace;

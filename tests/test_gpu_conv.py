@@ -39,6 +39,11 @@ CASES = [
     ("bigplane_stats", 8, 16, 3, 1, 1, 0, False, 0, True, 3, (2, 160, 112), False),
     ("bigplane_cfold", 2, 8, 7, 1, 3, 1, False, 0, True, 3, (1, 136, 128), False),
     ("bigplane_ct", 16, 8, 3, 2, 1, 0, True, 1, True, 3, (1, 72, 120), False),
+    # whole 8 x 128 tiles: bf16 takes the dedicated 2-channel 7x7 kernel (csrc/c7.hip), fp32 the generic W-fold path
+    ("c7fast_2to48", 2, 48, 7, 1, 3, 1, False, 0, True, 3, (2, 16, 128), False),
+    ("c7fast_2to96", 2, 96, 7, 1, 3, 1, False, 0, True, 3, (1, 8, 256), False),
+    ("c7fast_2to64", 2, 64, 7, 1, 3, 1, False, 0, True, 3, (1, 8, 128), False),
+    ("c7fast_2to32_noin", 2, 32, 7, 1, 3, 1, False, 0, False, 0, (1, 8, 128), False),
 ]
 
 
@@ -150,6 +155,30 @@ def test_conv_block(case, dtype):
         assert e["db_abs"] <= t["db_norm"] * noise, (name, e)
     else:
         assert e["db_abs"] <= gt * e["db_ref"] + t["db"] * noise, (name, e)
+
+
+def test_dedicated_c7_kernel_equals_generic_path():
+    """The 2-channel 7x7 layer on whole 8 x 128 tiles: dedicated kernel (csrc/c7.hip) vs the generic W-fold gather conv
+    it replaces, same bf16 inputs: outputs equal to bf16 rounding of the store, statistics-dependent normalised output too."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 2, 24, 256, generator=g)
+    x[:, 1] += 7.0                                                  # a channel with |mean| >> sigma (the dB spectrogram case)
+    w = torch.randn(48, 2, 7, 7, generator=g) * 0.1
+    b = torch.randn(48, generator=g)
+    res = []
+    for generic in (0, 1):
+        _lib.check(L.p2phd_set_option(b"c7_generic", generic))
+        try:
+            spec = _ops.ConvSpec(2, 48, 7, 1, 3, 1, False, 0, True, _ops.ACT_RELU)
+            with torch.no_grad():
+                yp = _ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, x.cuda()), w.cuda(), b.cuda(), spec)
+            res.append(yp.float().cpu())
+        finally:
+            _lib.check(L.p2phd_set_option(b"c7_generic", 0))
+    assert rel_err(res[0].numpy(), res[1].numpy()) < 6e-3            # two bf16 roundings of values that agree to fp32 accumulation order
+    assert float((res[0] - res[1]).abs().max()) < 0.1
 
 
 @pytest.mark.parametrize("bm", [128, 256, 192, 512])
