@@ -416,6 +416,7 @@ extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
+  if (thin_wgrad_kind(c)) return align256(thin_wgrad_workspace_floats(c) * sizeof(float));
   WgradSetup w;
   wgrad_setup(c, &w);
   size_t extra = 0;
@@ -431,6 +432,11 @@ static int conv_wgrad_impl(const p2phd_conv_desc* c, const void* x, const void* 
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   hipStream_t st = (hipStream_t)stream;
+  if (thin_wgrad_kind(c)) {                                       // dedicated kernel for the <= 4-channel layers (thinwgrad.hip)
+    if (int rc = thin_wgrad(c, x, dy, dw, accumulate, static_cast<float*>(workspace), st)) return rc;
+    if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, accumulate, st);
+    return P2PHD_OK;
+  }
   WgradSetup w;
   wgrad_setup(c, &w);
   float* dwp = static_cast<float*>(workspace);
