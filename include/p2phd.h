@@ -41,6 +41,12 @@ int p2phd_abi_version(void);
 int p2phd_device_info(char* name, int cap);
 /* tuning overrides for tests and A/B timing: "gconv_bm" = 0 (heuristic) | 128 | 256 */
 int p2phd_set_option(const char* name, int value);
+/* Measurement hook (bench.py's roofline): while armed, every launch of the implicit-GEMM conv kernel whose gathered
+ * tensor has `cin_pitch` channels, whose GEMM-K is `kk` and whose pixel grid is hg x wg is bracketed by HIP events on its
+ * own launch stream (the kernel alone: none of the companion launches of p2phd_conv_fwd).  p2phd_probe_read waits for
+ * the recorded events and returns up to `cap` durations in milliseconds; arm with enable = 0 to stop. */
+int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg);
+int p2phd_probe_read(float* ms_out, int cap);
 
 /* ------------------------------------------------------------------------------------------
  * MDCT4 / IMDCT4 (models/mdct.py:461-566).  n_fft a power of two in [16, 4096].

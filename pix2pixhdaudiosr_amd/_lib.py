@@ -22,6 +22,8 @@ SIGNATURES = {
     "p2phd_abi_version": (_i32, []),
     "p2phd_device_info": (_i32, [C.c_char_p, _i32]),
     "p2phd_set_option": (_i32, [C.c_char_p, _i32]),
+    "p2phd_probe_gconv": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "p2phd_probe_read": (_i32, [_vp, _i32]),
     "p2phd_mdct4_tables_floats": (C.c_size_t, [_i32]),
     "p2phd_mdct4_tables_fill": (_i32, [_i32, _vp]),
     "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),

@@ -28,6 +28,8 @@
 #include "common.h"
 #include "convplan.h"
 #include <cmath>
+#include <utility>
+#include <vector>
 #include <type_traits>
 
 namespace {
@@ -1211,6 +1213,14 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 // ------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------
+// measurement hook (p2phd_probe_gconv): events around matching launches, on the launch stream
+struct GconvProbe {
+  bool on = false;
+  int cp = 0, kk = 0, hg = 0, wg = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+GconvProbe g_probe_cfg;
+
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
 int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const float* bias, const void* addend, void* out,
                      float* stats, hipStream_t st, int* slot_rows) {
@@ -1229,7 +1239,12 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   const int mtiles = d.flat_m ? (int)(((long)d.N * npix + BM - 1) / BM) : ((npix + BM - 1) / BM) * d.N;
   const int ntiles = (d.n_extent + BN - 1) / BN;
   dim3 grid((unsigned)mtiles, (unsigned)ntiles);
+  const bool probe = g_probe_cfg.on && d.Cp_in == g_probe_cfg.cp && d.KK == g_probe_cfg.kk && d.Hg == g_probe_cfg.hg &&
+                     d.Wg == g_probe_cfg.wg && g_probe_cfg.ev.size() < 4096;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (probe) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
   hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
+  if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
 }
 
@@ -1474,6 +1489,27 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, in
 }
 
 }  // namespace p2phd
+
+extern "C" int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg) {
+  for (auto& e : g_probe_cfg.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+  g_probe_cfg.ev.clear();
+  g_probe_cfg.on = enable != 0;
+  g_probe_cfg.cp = cin_pitch; g_probe_cfg.kk = kk; g_probe_cfg.hg = hg; g_probe_cfg.wg = wg;
+  return P2PHD_OK;
+}
+
+extern "C" int p2phd_probe_read(float* ms_out, int cap) {
+  int n = 0;
+  for (auto& e : g_probe_cfg.ev) {
+    if (n >= cap) break;
+    if (hipEventSynchronize(e.second) != hipSuccess) break;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.first, e.second) != hipSuccess) break;
+    if (ms_out) ms_out[n] = ms;
+    ++n;
+  }
+  return n;
+}
 
 #ifdef P2PHD_PROBE
 extern "C" int p2phd_debug_probe(unsigned long long* out8, int reset) {

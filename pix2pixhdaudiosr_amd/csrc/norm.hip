@@ -561,6 +561,23 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
   }
 }
 
+// few slots (the residual trunk: 4-16 per sample): one THREAD per (sample, channel), consecutive threads on consecutive
+// channels (coalesced float2 reads), slots folded in order
+__global__ __launch_bounds__(256) void stats_merge_small_kernel(const float* __restrict__ table, float* __restrict__ stats, int slots,
+                                                                int ncls, int Cp, int C, long npix, int slot_rows) {
+  const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float cn = 0.f, cm = 0.f, cq = 0.f;
+  for (int s = 0; s < slots; ++s) {
+    const float cnt = (float)min((long)slot_rows, max(npix - (long)s * slot_rows, 0l));
+    for (int k = 0; k < ncls; ++k) {
+      const float2 v = *reinterpret_cast<const float2*>(table + 2 * ((((size_t)n * slots + s) * ncls + k) * Cp + c));
+      if (cnt > 0.f) chan_merge(cn, cm, cq, cnt, v.x / cnt, v.y);
+    }
+  }
+  *reinterpret_cast<float2*>(stats + 2 * ((size_t)n * Cp + c)) = make_float2(cm, cq);
+}
+
 __global__ __launch_bounds__(256) void stats_merge_kernel(const float* __restrict__ table, float* __restrict__ stats, int slots,
                                                           int ncls, int Cp, int C, long npix, int slot_rows) {
   const int n = blockIdx.y, lane = threadIdx.x & 63;
@@ -594,6 +611,11 @@ namespace p2phd {
 int launch_stats_merge(const float* table, float* stats, int N, int slots, int ncls, int Cp, int C, long npix, int slot_rows,
                        hipStream_t st) {
   if (N == 0 || slots == 0 || C == 0) return P2PHD_OK;
+  if (slots * ncls <= 32) {
+    hipLaunchKernelGGL(stats_merge_small_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)N), dim3(256), 0, st, table, stats, slots,
+                       ncls, Cp, C, npix, slot_rows);
+    return check_launch("stats_merge");
+  }
   hipLaunchKernelGGL(stats_merge_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)N), dim3(256), 0, st, table, stats, slots, ncls, Cp, C,
                      npix, slot_rows);
   return check_launch("stats_merge");
