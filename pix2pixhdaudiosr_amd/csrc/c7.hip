@@ -36,7 +36,8 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
 
 // Weights in fragment order: wf[((half * NB + nb) * 4 + s) * 64 + lane] = 8 bf16:
 //   A[row = l & 15][k = 32 s + 8 (l >> 4) + j],  k = dw * 16 + dh * 2 + c,  value w[16 (half * NB + nb) + row][c][dh][dw]
-__global__ void c7_pack_in_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, int K, int nblocks) {
+// dgrad = 1: the input gradient of Conv2d(K, 2, 7) as a 2 -> K convolution with w_eff[ch][c][dh][dw] = w[c][ch][6-dh][6-dw]
+__global__ void c7_pack_in_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, int K, int nblocks, int dgrad) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nblocks * 4 * 64) return;
   const int lane = idx & 63, s = (idx >> 6) & 3, blk = idx >> 8;
@@ -46,7 +47,8 @@ __global__ void c7_pack_in_kernel(const float* __restrict__ w, bf16_t* __restric
   for (int j = 0; j < 8; ++j) {
     const int dw = 2 * s + (g >> 1), dh = 4 * (g & 1) + (j >> 1), c = j & 1;
     const bool ok = ch < K && dh < 7 && dw < 7;
-    v[j] = (bf16_t)(ok ? w[((ch * 2 + c) * 7 + dh) * 7 + dw] : 0.f);
+    const int src = dgrad ? ((c * K + ch) * 7 + (6 - dh)) * 7 + (6 - dw) : ((ch * 2 + c) * 7 + dh) * 7 + dw;
+    v[j] = (bf16_t)(ok ? w[src] : 0.f);
   }
   *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
 }
@@ -60,7 +62,8 @@ __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, floa
 }
 
 // x [N,H,W,8] bf16 (channels 0,1 used) -> y [N,H,W,Cp] bf16, Cp = K (multiple of 16); grid (tiles, N, channel halves)
-template <int NB>
+// ZERO = true: zero padding instead of reflection (the input-gradient use, see c7_out_dgrad)
+template <int NB, bool ZERO>
 __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
                                                         const float* __restrict__ bias, bf16_t* __restrict__ y,
                                                         float* __restrict__ table, int H, int W, int Cp, int slots) {
@@ -95,8 +98,12 @@ __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict
     for (int it = 0; it < NIT; ++it) {
       const int e = min(tid + 256 * it, NE - 1);
       const int r = e / (TW + 8), c = e - r * (TW + 8);
-      const int hi = reflect_idx(h0 + r - 3, H), wi = reflect_idx(w0 + c - 3, W);
-      v[it] = xin[((size_t)hi * W + wi) * 4];
+      int hi = h0 + r - 3, wi = w0 + c - 3;
+      bool ok = true;
+      if constexpr (ZERO) { ok = hi >= 0 && hi < H && wi >= 0 && wi < W; hi = ok ? hi : 0; wi = ok ? wi : 0; }
+      else { hi = reflect_idx(hi, H); wi = reflect_idx(wi, W); }
+      const unsigned t = xin[((size_t)hi * W + wi) * 4];
+      v[it] = ok ? t : 0u;
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -215,9 +222,111 @@ __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict
   }
 }
 
+// Reflection adjoint of the input gradient of Conv2d(C, 2, 7) behind ReflectionPad2d(3): c7_in_fwd<ZERO> has written
+// dxpad at the interior positions; the padded frame folds onto the interior pixels within 3 of an edge,
+//   dx[i][j] += sum over the other preimages (ph, pw) of (i, j) under the reflection of dxpad[ph][pw],
+//   dxpad[p][c] = sum_{dh,dw,n} dy[ph - dh][pw - dw][n] w[n][c][dh][dw]   (dy zero outside the image).
+// One thread per (border pixel, 8-channel piece); the weights sit in LDS as [tap][n][C] f32, only the taps that reach into
+// the image are visited, dx is updated 16 bytes at a time.
+__global__ __launch_bounds__(256) void c7_out_dgrad_fix_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ w,
+                                                               bf16_t* __restrict__ dx, int N, int H, int W, int C) {
+  extern __shared__ float s_w[];                                  // [49][2][C]
+  for (int e = threadIdx.x; e < 49 * 2 * C; e += 256) {
+    const int c = e % C, n = (e / C) & 1, t = e / (2 * C);
+    s_w[e] = w[(n * C + c) * 49 + t];
+  }
+  __syncthreads();
+  const int cpr = C / 8;
+  const int nborder = 6 * W + 6 * (H - 6);
+  const long total = (long)N * nborder * cpr;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int pc = (int)(idx % cpr);
+  long r = idx / cpr;
+  const int e = (int)(r % nborder), n = (int)(r / nborder);
+  int i, j;
+  if (e < 6 * W) {
+    const int k = e / W;
+    i = k < 3 ? 1 + k : H - 7 + k;                              // rows 1,2,3, H-4,H-3,H-2
+    j = e - k * W;
+  } else {
+    const int e2 = e - 6 * W, k = e2 % 6, q = e2 / 6;           // the H - 6 rows outside the border rows: 0, 4 .. H-5, H-1
+    i = q == 0 ? 0 : (q <= H - 8 ? q + 3 : H - 1);
+    j = k < 3 ? 1 + k : W - 7 + k;
+  }
+  // preimages in padded coordinates: self, and the mirror if (i, j) lies within 3 of an edge (not on it)
+  int ph[2], pw[2], nh = 1, nw = 1;
+  ph[0] = i + 3; pw[0] = j + 3;
+  if (i >= 1 && i <= 3) ph[nh++] = 3 - i; else if (i >= H - 4 && i <= H - 2) ph[nh++] = 2 * H + 1 - i;
+  if (j >= 1 && j <= 3) pw[nw++] = 3 - j; else if (j >= W - 4 && j <= W - 2) pw[nw++] = 2 * W + 1 - j;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  const bf16_t* dyn = dy + (size_t)n * H * W * 8;               // channel pitch 8, channels 0,1
+  for (int a = 0; a < nh; ++a)
+    for (int b = 0; b < nw; ++b) {
+      if (a == 0 && b == 0) continue;
+      const int dh_lo = max(0, ph[a] - H + 1), dh_hi = min(6, ph[a]);
+      const int dw_lo = max(0, pw[b] - W + 1), dw_hi = min(6, pw[b]);
+      for (int dh = dh_lo; dh <= dh_hi; ++dh)
+        for (int dw = dw_lo; dw <= dw_hi; ++dw) {
+          const unsigned d2 = *reinterpret_cast<const unsigned*>(dyn + ((size_t)(ph[a] - dh) * W + (pw[b] - dw)) * 8);
+          const float d0 = __uint_as_float(d2 << 16), d1 = __uint_as_float(d2 & 0xFFFF0000u);
+          const float* w0 = s_w + ((dh * 7 + dw) * 2) * C + pc * 8;
+          const float4 a0 = *reinterpret_cast<const float4*>(w0), a1 = *reinterpret_cast<const float4*>(w0 + 4);
+          const float4 b0 = *reinterpret_cast<const float4*>(w0 + C), b1 = *reinterpret_cast<const float4*>(w0 + C + 4);
+          acc[0] += d0 * a0.x + d1 * b0.x; acc[1] += d0 * a0.y + d1 * b0.y; acc[2] += d0 * a0.z + d1 * b0.z; acc[3] += d0 * a0.w + d1 * b0.w;
+          acc[4] += d0 * a1.x + d1 * b1.x; acc[5] += d0 * a1.y + d1 * b1.y; acc[6] += d0 * a1.z + d1 * b1.z; acc[7] += d0 * a1.w + d1 * b1.w;
+        }
+    }
+  bf16_t* o = dx + (((size_t)n * H + i) * W + j) * C + pc * 8;  // channel pitch = C (multiple of 16)
+  uint4 v = *reinterpret_cast<const uint4*>(o);
+  bf16_t* vv = reinterpret_cast<bf16_t*>(&v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) vv[k] = (bf16_t)((float)vv[k] + acc[k]);
+  *reinterpret_cast<uint4*>(o) = v;
+}
+
 }  // namespace
 
 namespace p2phd {
+
+bool c7_out_dgrad_ok(const p2phd_conv_desc* c) {
+  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+         c->pad == 3 && c->pad_mode == 1 && c->C % 16 == 0 && c->C >= 16 && c->C <= 128 && (c->C <= 64 || c->C % 32 == 0) &&
+         c->H % TH == 0 && c->W % TW == 0 && c->H >= 8 && c->W >= 8;
+}
+
+size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c) { return (size_t)(c->C / 16) * 4 * 64 * 8; }
+
+int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st) {
+  const int nblocks = c->C / 16;
+  const int total = nblocks * 4 * 64;
+  hipLaunchKernelGGL(c7_pack_in_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, c->C, nblocks, 1);
+  return check_launch("c7_pack(dgrad)");
+}
+
+// dx [N,H,W,C] = input gradient of Conv2d(C, 2, 7) behind ReflectionPad2d(3); dy [N,H,W,8], w = master weights [2][C][7][7]
+int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st) {
+  const int halves = c->C > 64 ? 2 : 1;
+  const int nb = c->C / 16 / halves;
+  dim3 grid((unsigned)((c->H / TH) * (c->W / TW)), (unsigned)c->N, (unsigned)halves);
+#define P2PHD_C7D(NBV) hipLaunchKernelGGL((c7_in_fwd_kernel<NBV, true>), grid, dim3(256), 0, st, (const bf16_t*)dy, (const bf16_t*)wf, \
+                                          (const float*)nullptr, (bf16_t*)dx, (float*)nullptr, c->H, c->W, cpitch(c->C), 0)
+  switch (nb) {
+    case 1: P2PHD_C7D(1); break;
+    case 2: P2PHD_C7D(2); break;
+    case 3: P2PHD_C7D(3); break;
+    case 4: P2PHD_C7D(4); break;
+    default: set_error("c7_out_dgrad: unsupported channel count %d", c->C); return P2PHD_EUNSUPPORTED;
+  }
+#undef P2PHD_C7D
+  if (int rc = check_launch("c7_out_dgrad")) return rc;
+  const long total = (long)c->N * (6 * c->W + 6 * (c->H - 6)) * (c->C / 8);
+  hipLaunchKernelGGL(c7_out_dgrad_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 49 * 2 * c->C * sizeof(float), st, (const bf16_t*)dy, w_master,
+                     (bf16_t*)dx, c->N, c->H, c->W, c->C);
+  return check_launch("c7_out_dgrad_fix");
+}
 
 bool c7_in_ok(const p2phd_conv_desc* c) {
   return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->C == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
@@ -230,7 +339,7 @@ size_t c7_in_packed_elems(const p2phd_conv_desc* c) { return (size_t)(c->K / 16)
 int c7_in_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st) {
   const int nblocks = c->K / 16;
   const int total = nblocks * 4 * 64;
-  hipLaunchKernelGGL(c7_pack_in_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, c->K, nblocks);
+  hipLaunchKernelGGL(c7_pack_in_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, c->K, nblocks, 0);
   return check_launch("c7_pack");
 }
 
@@ -242,7 +351,7 @@ int c7_in_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const flo
   const int nb = c->K / 16 / halves;
   dim3 grid((unsigned)((c->H / TH) * (c->W / TW)), (unsigned)c->N, (unsigned)halves);
   const int slots = c7_in_slots(c);
-#define P2PHD_C7(NBV) hipLaunchKernelGGL(c7_in_fwd_kernel<NBV>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, bias, \
+#define P2PHD_C7(NBV) hipLaunchKernelGGL((c7_in_fwd_kernel<NBV, false>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, bias, \
                                          (bf16_t*)y, table, c->H, c->W, cpitch(c->K), slots)
   switch (nb) {
     case 1: P2PHD_C7(1); break;

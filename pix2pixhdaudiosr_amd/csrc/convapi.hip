@@ -55,6 +55,14 @@ bool c7_fast_shape(const p2phd_conv_desc* c) {
   return ok;
 }
 
+bool c7_dgrad_shape(const p2phd_conv_desc* c) {
+  const int keep = g_opt_c7_generic;
+  g_opt_c7_generic = 0;
+  const bool ok = c7_out_dgrad_ok(c);
+  g_opt_c7_generic = keep;
+  return ok;
+}
+
 int fold_mode(const p2phd_conv_desc* c) {
   if (c->transposed || c->stride != 1) return FOLD_NONE;
   if (c->K <= 4 && c->S * c->K <= 32) return FOLD_OUT;
@@ -249,6 +257,8 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
   if (which == 0 && c7_fast_shape(c)) n += c7_in_packed_elems(c);           // fragment-ordered copy for c7.hip, behind the W-fold pack
+  if (which == 1 && c7_dgrad_shape(c))                                       // + fragment-ordered copy + f32 master copy (border fix)
+    return (n + c7_out_dgrad_packed_elems(c)) * elem_size(c->dtype) + (size_t)c->K * c->C * c->R * c->S * sizeof(float);
   return n * elem_size(c->dtype);
 }
 
@@ -271,6 +281,17 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
     size_t n = 0;
     for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
     return c7_in_pack(c, w, static_cast<char*>(packed) + n * elem_size(c->dtype), (hipStream_t)stream);
+  }
+  if (which == 1 && c7_dgrad_shape(c)) {
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    char* frag = static_cast<char*>(packed) + n * elem_size(c->dtype);
+    if (int rc = c7_out_dgrad_pack(c, w, frag, (hipStream_t)stream)) return rc;
+    char* master = frag + c7_out_dgrad_packed_elems(c) * elem_size(c->dtype);
+    if (hipMemcpyAsync(master, w, (size_t)c->K * c->C * c->R * c->S * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+      set_error("pack_weights: copy of the master weights failed");
+      return P2PHD_ELAUNCH;
+    }
   }
   return P2PHD_OK;
 }
@@ -372,6 +393,15 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
   out_size(c, &Ho, &Wo);
   const bool reflect = c->pad_mode == 1;
   const bool kfold = fold_mode(c) == FOLD_OUT;
+  if (addend == nullptr && c7_out_dgrad_ok(c)) {
+    // Conv2d(ngf, 2, 7): the dedicated 2 -> ngf kernel with flipped weights and zero padding + the reflection fold of
+    // the 3-pixel frame (c7.hip); no padded-grid tensor, no fold pass over the whole gradient
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    const char* frag = static_cast<const char*>(wp) + n * elem_size(c->dtype);
+    const float* master = reinterpret_cast<const float*>(frag + c7_out_dgrad_packed_elems(c) * elem_size(c->dtype));
+    return c7_out_dgrad(c, dy, frag, master, dx, st);
+  }
   P2PHD_REQUIRE(!(reflect || kfold) || workspace, "conv_dgrad: this layer needs p2phd_conv_dgrad_workspace_bytes of scratch");
   char* ws = static_cast<char*>(workspace);
   void* dxp = ws;                                   // padded-grid gradient (reflect only)

@@ -48,6 +48,10 @@ size_t c7_in_packed_elems(const p2phd_conv_desc* c);
 int c7_in_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_in_slots(const p2phd_conv_desc* c);
 int c7_in_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, void* y, float* table, hipStream_t st);
+bool c7_out_dgrad_ok(const p2phd_conv_desc* c);
+size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
+int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
+int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
 // thinwgrad.hip: weight gradient of the layers with <= 4 channels on one side (bf16); kind 0 = not eligible
 int thin_wgrad_kind(const p2phd_conv_desc* c);
 size_t thin_wgrad_workspace_floats(const p2phd_conv_desc* c);

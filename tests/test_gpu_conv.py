@@ -44,6 +44,10 @@ CASES = [
     ("c7fast_2to96", 2, 96, 7, 1, 3, 1, False, 0, True, 3, (1, 8, 256), False),
     ("c7fast_2to64", 2, 64, 7, 1, 3, 1, False, 0, True, 3, (1, 8, 128), False),
     ("c7fast_2to32_noin", 2, 32, 7, 1, 3, 1, False, 0, False, 0, (1, 8, 128), False),
+    # the generator head on whole tiles: bf16 input gradient = the same kernel with flipped weights + reflection fold of the frame
+    ("c7fast_48to2_tanh", 48, 2, 7, 1, 3, 1, False, 0, False, 2, (2, 16, 128), False),
+    ("c7fast_96to2_tanh", 96, 2, 7, 1, 3, 1, False, 0, False, 2, (1, 8, 256), False),
+    ("c7fast_32to2_tanh", 32, 2, 7, 1, 3, 1, False, 0, False, 2, (1, 24, 128), False),
 ]
 
 
