@@ -28,6 +28,12 @@ constexpr int LPITCH = 140;                // dwords per LDS input row: >= TW + 
 // 8-byte writes of 16 pixel lanes over the banks (pitch in dwords = 12, 20, 28, 44: 2-way at worst)
 constexpr int srow_bytes(int nb) { return nb == 4 ? 176 : nb * 32 + 16; }
 
+// Hand-over of LDS data between the lanes of ONE wave: LDS executes a wave's operations in order, so all that is needed is
+// that the compiler keeps the order (memory clobber) and that earlier LDS operations have completed.  Deliberately NOT a
+// wavefront-scope fence: that lowers to s_waitcnt vmcnt(0) as well, i.e. it waits for every global load and store in
+// flight -- the row prefetch of c7_out_fwd and the output stores of c7_in_fwd ran at one memory round trip per step.
+__device__ __forceinline__ void lds_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {
   if (i < 0) i = -i;
   if (i >= n) i = 2 * (n - 1) - i;
@@ -173,9 +179,7 @@ __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict
       }
     }
     first = false;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    lds_wave_sync();
     // 64 pixels x (NB * 32) bytes leave as consecutive 16-byte pieces of consecutive NHWC rows
     constexpr int CPP = NB * 2;                                  // 16-byte pieces per pixel (of this channel half)
     bf16_t* orow = y + (((size_t)n * H + h0 + row) * W + w0 + col0) * Cp + ch0;
@@ -186,9 +190,7 @@ __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict
       const uint4 v = *reinterpret_cast<const uint4*>(stage + px * SROW + pc * 16);
       *reinterpret_cast<uint4*>(orow + (size_t)px * Cp + pc * 8) = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    lds_wave_sync();
   }
 
   if (table != nullptr) {
@@ -287,6 +289,163 @@ __global__ __launch_bounds__(256) void c7_out_dgrad_fix_kernel(const bf16_t* __r
   *reinterpret_cast<uint4*>(o) = v;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Conv2d(C, 2, 7) behind ReflectionPad2d(3) (+ bias, Tanh): the generator head, forward.
+// The horizontal taps ride on the GEMM's reduction axis, the vertical ones on its rows:
+//   Z[(dh, n)][qw] = sum_{dw, c} w[n][c][dh][dw] x[r][qw + dw - 3][c]        (A = 16 x 7C weights, resident in registers;
+//                                                                            B fragment = one 16-byte piece of pixel qw+dw-3)
+//   out[r - dh + 3][qw][n] += Z[(dh, n)][qw]                                 (14 LDS adds per input pixel)
+// A workgroup owns a strip of 128 columns and marches down kRowsOut output rows: every input row is read from HBM once
+// (plus 6 halo rows per segment), staged in LDS one row ahead, and each wave keeps to its own 32 columns, so output
+// rows are finished, biased, squashed and stored by the wave that accumulated them: one barrier per row.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kRowsOut = 32;
+constexpr int kStripW = 128;
+
+// native vector type, not HIP's uint4 struct: a struct copied global -> private -> LDS stays two memcpys in the IR that
+// SROA does not break up, i.e. both prefetch sets lived in scratch memory (and scratch traffic queues on vmcnt right
+// behind the prefetch it was meant to hide: the kernel ran at one memory round trip per row)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int NLD>
+__device__ __forceinline__ void row_fetch(u32x4 (&v)[NLD], const bf16_t* __restrict__ row, const int (&src)[NLD]) {
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) v[i] = *reinterpret_cast<const u32x4*>(row + src[i]);
+}
+template <int NLD>
+__device__ __forceinline__ void row_commit(unsigned char* __restrict__ dst, const u32x4 (&v)[NLD], const int (&off)[NLD]) {
+#pragma unroll
+  for (int i = 0; i < NLD; ++i)
+    if (off[i] >= 0) *reinterpret_cast<u32x4*>(dst + off[i]) = v[i];
+}
+
+// wf[s][lane] = 8 bf16: A[row = l & 15][k = 32 s + 8 (l >> 4) + j], row = dh * 2 + n, k = dw * C + c
+__global__ void c7_pack_out_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, int C, int ksteps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= ksteps * 64) return;
+  const int lane = idx & 63, s = idx >> 6;
+  const int row = lane & 15, g = lane >> 4;
+  const int dh = row >> 1, n = row & 1;
+  bf16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 32 * s + 8 * g + j;
+    const int dw = k / C, c = k - dw * C;
+    const bool ok = dh < 7 && dw < 7;
+    v[j] = (bf16_t)(ok ? w[((n * C + c) * 7 + dh) * 7 + dw] : 0.f);
+  }
+  *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void c7_out_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wf,
+                                                         const float* __restrict__ bias, bf16_t* __restrict__ y, int H, int W,
+                                                         int act, int abl) {
+  constexpr int KS = (7 * C + 31) / 32;                         // k-steps of 32
+  constexpr int PPX = C / 8;                                    // 16-byte pieces per pixel
+  constexpr int ROWPX = kStripW + 6;
+  constexpr int ROWB = ROWPX * C * 2;                           // bytes of one staged input row
+  constexpr int NLD = (ROWPX * PPX + 255) / 256;                // pieces per thread and row
+  __shared__ __attribute__((aligned(16))) unsigned char s_x[2][ROWB + 16];   // + one zero piece for the K tail
+  __shared__ float s_acc[8][kStripW][2];                        // output rows in flight (ring of 8)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strips = W / kStripW;
+  const int st = blockIdx.x % strips, seg = blockIdx.x / strips;
+  const int n = blockIdx.y;
+  const int w0 = st * kStripW, q0 = seg * kRowsOut;
+  const int q1 = min(q0 + kRowsOut, H);
+
+  bf16x8 wa[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wa[s] = *reinterpret_cast<const bf16x8*>(wf + ((size_t)s * 64 + lane) * 8);
+  for (int e = tid; e < 8 * kStripW * 2; e += 256) (&s_acc[0][0][0])[e] = 0.f;
+  if (tid < 2) { *reinterpret_cast<uint4*>(s_x[tid] + ROWB) = make_uint4(0u, 0u, 0u, 0u); }
+
+  // this thread's pieces of a staged row: pixel (with the column reflection folded in) and piece index
+  int src_off[NLD], dst_off[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int e = tid + 256 * i;
+    const int px = e / PPX, pc = e - px * PPX;
+    const int wi = reflect_idx(w0 + min(px, ROWPX - 1) - 3, W);
+    src_off[i] = (wi * C + pc * 8);
+    dst_off[i] = e < ROWPX * PPX ? (px * C + pc * 8) * 2 : -1;
+  }
+  const bf16_t* xn = x + (size_t)n * H * W * C;
+  const int p = lane & 15, g = lane >> 4;
+  const int r_first = q0 - 3, r_last = q1 - 1 + 3;             // input rows this segment touches
+  // rows are fetched TWO steps ahead into two alternating register sets (one step of ~0.3 us does not cover the memory
+  // latency; with four workgroups per CU two rows each keep ~100 KB in flight per CU)
+  u32x4 preA[NLD], preB[NLD];
+  // rows past the segment are clamped to its last row (loaded, never used): every step runs the same code
+  auto rowp = [&](int r) { return xn + (size_t)reflect_idx(min(r, r_last), H) * W * C; };
+  row_fetch<NLD>(preA, rowp(r_first), src_off);
+  __syncthreads();
+  row_commit<NLD>(s_x[0], preA, dst_off);
+  row_fetch<NLD>(preA, rowp(r_first + 1), src_off);             // committed at the first step
+  row_fetch<NLD>(preB, rowp(r_first + 2), src_off);             // committed at the second step
+  const float b0 = bias != nullptr ? bias[0] : 0.f, b1 = bias != nullptr ? bias[1] : 0.f;
+
+  // always_inline: called twice per iteration; out of line, every array it captures (the weights!) lives in scratch
+  auto compute_row = [&](int r, int buf) __attribute__((always_inline)) {
+    const unsigned char* xr = s_x[buf];
+    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const int qwA = (wave * 2) * 16, qwB = qwA + 16;
+    // the two 16-column blocks of the wave as two independent accumulation chains
+    if (!(abl & 1))
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      // k = dw * C + c and the staged row is [pixel][C]: the fragment of k-chunk kc for output column qw is the 16
+      // bytes at element (qw * C + kc) -- a shift by dw pixels IS a shift by dw * C elements; the K tail reads zeros
+      const int kc = 32 * s + 8 * g;
+      const int offA = kc < 7 * C ? ((qwA + p) * C + kc) * 2 : ROWB;
+      const int offB = kc < 7 * C ? ((qwB + p) * C + kc) * 2 : ROWB;
+      const bf16x8 fa = *reinterpret_cast<const bf16x8*>(xr + offA);
+      const bf16x8 fb = *reinterpret_cast<const bf16x8*>(xr + offB);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], fa, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], fb, acc[1], 0, 0, 0);
+    }
+    // rows (dh, n) = 4 g + reg: dh = 2 g + (reg >> 1), n = reg & 1; output row q = r - dh + 3
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int dh = 2 * g + (reg >> 1), nn = reg & 1;
+        const int q = r - dh + 3;
+        if (dh < 7 && q >= q0 && q < q1 && !(abl & 2)) s_acc[q & 7][(cb ? qwB : qwA) + p][nn] += acc[cb][reg];
+      }
+    // output row q = r - 3 has now received its 7 contributions; each wave finishes its own 32 columns
+    const int q = r - 3;
+    if (q >= q0 && q < q1) {
+      lds_wave_sync();
+      if (lane < 32) {
+        const int col = wave * 32 + lane;
+        float v0 = s_acc[q & 7][col][0] + b0, v1 = s_acc[q & 7][col][1] + b1;
+        s_acc[q & 7][col][0] = 0.f; s_acc[q & 7][col][1] = 0.f;
+        if (act == P2PHD_ACT_TANH) { v0 = tanhf(v0); v1 = tanhf(v1); }
+        else if (act == P2PHD_ACT_RELU) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+        else if (act == P2PHD_ACT_LRELU) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
+        const bf16_t o0 = (bf16_t)v0, o1 = (bf16_t)v1;
+        const unsigned lo = (unsigned)__builtin_bit_cast(unsigned short, o0) | ((unsigned)__builtin_bit_cast(unsigned short, o1) << 16);
+        *reinterpret_cast<uint4*>(y + (((size_t)n * H + q) * W + w0 + col) * 8) = make_uint4(lo, 0u, 0u, 0u);
+      }
+      lds_wave_sync();
+    }
+  };
+
+  // two steps per iteration so that the register sets are indexed statically
+  for (int r = r_first; r <= r_last; r += 2) {
+    __syncthreads();                                            // row r is staged; everybody is done with the other buffer
+    row_commit<NLD>(s_x[1], preA, dst_off);
+    if (!(abl & 4)) row_fetch<NLD>(preA, rowp(r + 3), src_off);
+    compute_row(r, 0);
+    __syncthreads();
+    row_commit<NLD>(s_x[0], preB, dst_off);
+    if (!(abl & 4)) row_fetch<NLD>(preB, rowp(r + 4), src_off);
+    if (r + 1 <= r_last) compute_row(r + 1, 1);
+  }
+}
+
 }  // namespace
 
 namespace p2phd {
@@ -326,6 +485,37 @@ int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const
   hipLaunchKernelGGL(c7_out_dgrad_fix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 49 * 2 * c->C * sizeof(float), st, (const bf16_t*)dy, w_master,
                      (bf16_t*)dx, c->N, c->H, c->W, c->C);
   return check_launch("c7_out_dgrad_fix");
+}
+
+bool c7_out_ok(const p2phd_conv_desc* c) {
+  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+         c->pad == 3 && c->pad_mode == 1 && (c->C == 32 || c->C == 48 || c->C == 64 || c->C == 96 || c->C == 128) &&
+         c->W % kStripW == 0 && c->H >= 8;
+}
+
+size_t c7_out_packed_elems(const p2phd_conv_desc* c) { return (size_t)((7 * c->C + 31) / 32) * 64 * 8; }
+
+int c7_out_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st) {
+  const int ksteps = (7 * c->C + 31) / 32;
+  hipLaunchKernelGGL(c7_pack_out_kernel, dim3((ksteps * 64 + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, c->C, ksteps);
+  return check_launch("c7_pack(out)");
+}
+
+// y [N,H,W,8] = act(conv7x7(reflect_pad3(x [N,H,W,C])) + bias), two output channels
+int c7_out_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, int act, void* y, hipStream_t st) {
+  dim3 grid((unsigned)((c->W / kStripW) * ((c->H + kRowsOut - 1) / kRowsOut)), (unsigned)c->N);
+#define P2PHD_C7O(CV) hipLaunchKernelGGL(c7_out_fwd_kernel<CV>, grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)wf, bias, \
+                                         (bf16_t*)y, c->H, c->W, act, g_opt_c7_abl)
+  switch (c->C) {
+    case 32: P2PHD_C7O(32); break;
+    case 48: P2PHD_C7O(48); break;
+    case 64: P2PHD_C7O(64); break;
+    case 96: P2PHD_C7O(96); break;
+    case 128: P2PHD_C7O(128); break;
+    default: set_error("c7_out_fwd: unsupported channel count %d", c->C); return P2PHD_EUNSUPPORTED;
+  }
+#undef P2PHD_C7O
+  return check_launch("c7_out_fwd");
 }
 
 bool c7_in_ok(const p2phd_conv_desc* c) {

@@ -55,6 +55,14 @@ bool c7_fast_shape(const p2phd_conv_desc* c) {
   return ok;
 }
 
+bool c7_out_shape(const p2phd_conv_desc* c) {
+  const int keep = g_opt_c7_generic;
+  g_opt_c7_generic = 0;
+  const bool ok = c7_out_ok(c);
+  g_opt_c7_generic = keep;
+  return ok;
+}
+
 bool c7_dgrad_shape(const p2phd_conv_desc* c) {
   const int keep = g_opt_c7_generic;
   g_opt_c7_generic = 0;
@@ -257,6 +265,7 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
   if (which == 0 && c7_fast_shape(c)) n += c7_in_packed_elems(c);           // fragment-ordered copy for c7.hip, behind the W-fold pack
+  if (which == 0 && c7_out_shape(c)) n += c7_out_packed_elems(c);
   if (which == 1 && c7_dgrad_shape(c))                                       // + fragment-ordered copy + f32 master copy (border fix)
     return (n + c7_out_dgrad_packed_elems(c)) * elem_size(c->dtype) + (size_t)c->K * c->C * c->R * c->S * sizeof(float);
   return n * elem_size(c->dtype);
@@ -281,6 +290,11 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
     size_t n = 0;
     for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
     return c7_in_pack(c, w, static_cast<char*>(packed) + n * elem_size(c->dtype), (hipStream_t)stream);
+  }
+  if (which == 0 && c7_out_shape(c)) {
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    return c7_out_pack(c, w, static_cast<char*>(packed) + n * elem_size(c->dtype), (hipStream_t)stream);
   }
   if (which == 1 && c7_dgrad_shape(c)) {
     size_t n = 0;
@@ -332,6 +346,11 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
   const int fold = fold_mode(c);
   P2PHD_REQUIRE((fold == FOLD_NONE && stats == nullptr) || workspace,
                 "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch (W-fold image / statistics partials)");
+  if (fold == FOLD_OUT && stats == nullptr && c7_out_ok(c)) {     // the generator head: marching kernel of c7.hip
+    size_t n = 0;
+    for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+    return c7_out_fwd(c, x, static_cast<const char*>(wp) + n * elem_size(c->dtype), bias, act, y, st);
+  }
   if (fold == FOLD_OUT) {
     Plan& p = plans[0];
     if (int rc = launch_gconv(p.d, c->dtype, x, wp, nullptr, nullptr, workspace, nullptr, st)) return rc;

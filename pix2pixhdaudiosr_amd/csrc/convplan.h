@@ -40,7 +40,8 @@ inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
-extern int g_opt_c7_generic;      // 1: the 7x7 2-channel layers always take the generic W-fold path
+extern int g_opt_c7_generic;
+extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 
 // c7.hip: dedicated bf16 kernels of the generator's 7x7 end layers (full tiles of 8 x 128 pixels only)
 bool c7_in_ok(const p2phd_conv_desc* c);
@@ -48,6 +49,10 @@ size_t c7_in_packed_elems(const p2phd_conv_desc* c);
 int c7_in_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_in_slots(const p2phd_conv_desc* c);
 int c7_in_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, void* y, float* table, hipStream_t st);
+bool c7_out_ok(const p2phd_conv_desc* c);
+size_t c7_out_packed_elems(const p2phd_conv_desc* c);
+int c7_out_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
+int c7_out_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, int act, void* y, hipStream_t st);
 bool c7_out_dgrad_ok(const p2phd_conv_desc* c);
 size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);

@@ -29,12 +29,9 @@ constexpr int kWaves = 4;
 constexpr int kFramesPerWave = 2;
 constexpr int kFramesPerWG = kWaves * kFramesPerWave;
 
-__device__ __forceinline__ void wave_sync() {
-  // LDS executes one wave's operations in order; this only stops the compiler from moving them across each other
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+// LDS executes one wave's operations in order; this keeps the compiler from moving them across each other and waits for
+// the wave's earlier LDS operations only (a wavefront-scope fence would also wait for every global load / store in flight)
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ int sf(int n) { return n ^ ((n >> 5) & 1); }                 // float image
 __device__ __forceinline__ int sc(int i) { return i ^ (((i >> 4) & 3) * 5); }           // complex exchange image
