@@ -268,6 +268,14 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     if constexpr (sizeof(T) == 2) {
 #ifdef P2PHD_ABL_NOMFMA
       asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
+#elif defined(P2PHD_ABL_MFMA16)
+      // timing experiment only (wrong numbers): the same MACs as two v_mfma_f32_16x16x32_bf16 on the same registers
+      {
+        typedef __attribute__((ext_vector_type(4))) float f32x4_;
+        f32x4_* q = reinterpret_cast<f32x4_*>(&acc[i][j]);
+        q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]), *reinterpret_cast<bf16x8*>(&bfr[buf][j]), q[0], 0, 0, 0);
+        q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]), *reinterpret_cast<bf16x8*>(&bfr[buf][j]), q[1], 0, 0, 0);
+      }
 #else
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
                                                           *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);

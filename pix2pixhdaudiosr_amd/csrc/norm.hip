@@ -568,11 +568,18 @@ __global__ __launch_bounds__(256) void stats_merge_small_kernel(const float* __r
   const int n = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   float cn = 0.f, cm = 0.f, cq = 0.f;
-  for (int s = 0; s < slots; ++s) {
-    const float cnt = (float)min((long)slot_rows, max(npix - (long)s * slot_rows, 0l));
-    for (int k = 0; k < ncls; ++k) {
-      const float2 v = *reinterpret_cast<const float2*>(table + 2 * ((((size_t)n * slots + s) * ncls + k) * Cp + c));
-      if (cnt > 0.f) chan_merge(cn, cm, cq, cnt, v.x / cnt, v.y);
+  const int total = slots * ncls;                               // partial index e = s * ncls + k
+  const float2* tp = reinterpret_cast<const float2*>(table) + (size_t)n * total * Cp + c;
+  for (int e0 = 0; e0 < total; e0 += 8) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = tp[(size_t)min(e0 + u, total - 1) * Cp];   // eight independent loads in flight
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u;
+      const int sl = e / ncls;
+      const float cnt = (float)min((long)slot_rows, max(npix - (long)sl * slot_rows, 0l));
+      if (e < total && cnt > 0.f) chan_merge(cn, cm, cq, cnt, v[u].x / cnt, v[u].y);
     }
   }
   *reinterpret_cast<float2*>(stats + 2 * ((size_t)n * Cp + c)) = make_float2(cm, cq);
