@@ -143,6 +143,20 @@ size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_fwd, const float* bias, int act,
                    void* y, float* stats, void* workspace, void* stream);
 
+/* fp8 forward of the wide stride-1 layers (BASELINE configs[4]: bf16 + fp8 MFMA conv weights; the reference analogue is its
+ * AMP path, train.py:62-67,148-149).  Operands are OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8, accumulation fp32, outputs bf16;
+ * fp32 master weights, the bf16 activations and the whole backward pass are unchanged.
+ *   p2phd_conv_fp8_eligible   : 1 if the layer can run this way (Conv2d, stride 1, C %% 16 == 0, R*S*C %% 128 == 0, desc.dtype BF16)
+ *   p2phd_conv_fp8_pack_weights: per-layer scale = max|w| / 448 found on the device (no host sync), weights quantised into
+ *                               `packed8` (p2phd_conv_fp8_packed_bytes); repack after every optimizer step
+ *   p2phd_conv_fwd_fp8        : x8 = the e4m3 twin of the bf16 input written by p2phd_instnorm_act_fwd_q8 (scale 1);
+ *                               y, stats, workspace as for p2phd_conv_fwd */
+int p2phd_conv_fp8_eligible(const p2phd_conv_desc* c);
+size_t p2phd_conv_fp8_packed_bytes(const p2phd_conv_desc* c);
+int p2phd_conv_fp8_pack_weights(const p2phd_conv_desc* c, const float* w, void* packed8, void* stream);
+int p2phd_conv_fwd_fp8(const p2phd_conv_desc* c, const void* x8, const void* packed8, const float* bias, int act,
+                       void* y, float* stats, void* workspace, void* stream);
+
 /* dx = conv^T(dy) (+ addend, same layout as dx).  Replaces autograd of F.conv2d / F.conv_transpose2d and, for
  * pad_mode = 1, of ReflectionPad2d as well (needs p2phd_conv_dgrad_workspace_bytes of scratch). */
 size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c);
@@ -167,6 +181,10 @@ int p2phd_conv_wgrad_acc(const p2phd_conv_desc* c, const void* x, const void* dy
  * residual != NULL.  stats = the float [N][Cp][2] (mean, sum of squared deviations) p2phd_conv_fwd wrote. */
 int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
                            int N, int64_t HW, int C, float eps, int act, void* stream);
+/* Same, and additionally out8 = out as OCP e4m3 bytes (scale 1, saturated at +-448; dtype must be BF16): the operand of
+ * the next layer's p2phd_conv_fwd_fp8. */
+int p2phd_instnorm_act_fwd_q8(int dtype, const void* y, const float* stats, const void* residual, void* out, void* out8,
+                              int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dy from g = dL/d(out) through act and InstanceNorm; bstats: float [N][Cp][2] scratch (zeroed inside).
  * db (float [C], may be NULL): the conv bias gradient = column sums of dy, accumulated in the same pass. */
 int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,

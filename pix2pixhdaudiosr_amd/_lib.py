@@ -39,12 +39,17 @@ SIGNATURES = {
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_fp8_eligible": (_i32, [_vp]),
+    "p2phd_conv_fp8_packed_bytes": (C.c_size_t, [_vp]),
+    "p2phd_conv_fp8_pack_weights": (_i32, [_vp, _vp, _vp, _vp]),
+    "p2phd_conv_fwd_fp8": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "p2phd_conv_dgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_acc": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_instnorm_act_fwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
+    "p2phd_instnorm_act_fwd_q8": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -300,6 +300,31 @@ class ConvSpec:
         self.transposed, self.opad = transposed, opad
         self.norm, self.act = norm, act
         self._packed = {}
+        # fp8 forward (networks.enable_fp8): `fp8` = run this layer's forward on e4m3 operands when the input carries an
+        # e4m3 twin; `emit_q8` = the InstanceNorm pass of this layer also writes the e4m3 twin of its output
+        self.fp8 = False
+        self.emit_q8 = False
+        self._q8_out = None
+
+    def fp8_ok(self, N, H, W):
+        d = self.desc(N, H, W, torch.bfloat16)
+        return bool(lib().p2phd_conv_fp8_eligible(C.byref(d)))
+
+    def packed_fp8(self, weight, d):
+        """e4m3 weights + per-layer scale (found on the device); re-quantised when the master copy changed."""
+        key = ("fp8", d.dtype)
+        stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        nbytes = lib().p2phd_conv_fp8_packed_bytes(C.byref(d))
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
+        w = weight.detach()
+        if w.dtype != torch.float32 or not w.is_contiguous():
+            w = w.float().contiguous()
+        check(lib().p2phd_conv_fp8_pack_weights(C.byref(d), ptr(w), ptr(buf), stream_ptr()), "conv_fp8_pack_weights")
+        self._packed[key] = (stamp, buf)
+        return buf
 
     def desc(self, N, H, W, dtype):
         return ConvDesc(N, self.cin, H, W, self.cout, self.k, self.k, self.stride, self.pad, self.pad_mode,
@@ -339,7 +364,8 @@ class ConvBlockFn(torch.autograd.Function):
         Ho, Wo = spec.out_size(d)
         L = lib()
         Cp_out = cpitch(spec.cout)
-        wp = spec.packed(weight, 0, d)
+        x8 = getattr(x, "_p2phd_q8", None) if (spec.fp8 and x.dtype == torch.bfloat16) else None
+        wp = spec.packed_fp8(weight, d) if x8 is not None else spec.packed(weight, 0, d)
         b = None if bias is None else bias.detach().float().contiguous()
         y = empty((N, Ho, Wo, Cp_out), x.dtype, x.device)
         stats = zeros((N, Cp_out, 2), x.device) if spec.norm else None
@@ -352,15 +378,24 @@ class ConvBlockFn(torch.autograd.Function):
             e0.record()
         else:
             e0 = None
-        check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
+        if x8 is not None:
+            check(L.p2phd_conv_fwd_fp8(C.byref(d), ptr(x8), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd_fp8")
+        else:
+            check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
         if e0 is not None:
             e1.record()
             _KERNEL_PROBE["events"].append((e0, e1))
         if spec.norm:
             res = None if residual is None else phys(residual, "residual")
             out = empty_like(y)
-            check(L.p2phd_instnorm_act_fwd(d.dtype, ptr(y), ptr(stats), ptr(res), ptr(out), N, Ho * Wo, spec.cout, IN_EPS,
-                                           spec.act, stream_ptr()), "instnorm_act_fwd")
+            if spec.emit_q8 and y.dtype == torch.bfloat16:
+                out8 = empty(tuple(y.shape), torch.uint8, y.device)
+                check(L.p2phd_instnorm_act_fwd_q8(d.dtype, ptr(y), ptr(stats), ptr(res), ptr(out), ptr(out8), N, Ho * Wo, spec.cout,
+                                                  IN_EPS, spec.act, stream_ptr()), "instnorm_act_fwd_q8")
+                spec._q8_out = out8
+            else:
+                check(L.p2phd_instnorm_act_fwd(d.dtype, ptr(y), ptr(stats), ptr(res), ptr(out), N, Ho * Wo, spec.cout, IN_EPS,
+                                               spec.act, stream_ptr()), "instnorm_act_fwd")
         else:
             if residual is not None:
                 raise _lib.P2PHDError("residual add is only fused behind InstanceNorm")
@@ -464,7 +499,10 @@ class SkipLink:
 def conv_block(x, weight, bias, spec, residual=None, link=None):
     if link is not None and residual is None:
         link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
-    return ConvBlockFn.apply(x, weight, bias, residual, spec, link)
+    out = ConvBlockFn.apply(x, weight, bias, residual, spec, link)
+    if spec._q8_out is not None:                                    # e4m3 twin of this output for the next layer's fp8 forward
+        out._p2phd_q8, spec._q8_out = spec._q8_out, None
+    return out
 
 
 # ------------------------------------------------------------------------------------------

@@ -47,6 +47,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPP = 4; };    // elements per 16-byte piece
 template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
+// OCP e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8): 16 per 16-byte piece; results leave as bf16
+struct fp8_t { unsigned char v; };
+template <> struct Elem<fp8_t> { static constexpr int EPP = 16; };
+template <typename T> struct OutOf { typedef T type; };
+template <> struct OutOf<fp8_t> { typedef bf16_t type; };
 
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
@@ -82,8 +87,11 @@ __device__ unsigned long long g_probe[kProbeSlots * 8];   // one record per work
 
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
 __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
-                                                    const float* __restrict__ bias, const T* __restrict__ addend,
-                                                    T* __restrict__ out, float* __restrict__ stats) {
+                                                    const float* __restrict__ bias,
+                                                    const typename OutOf<T>::type* __restrict__ addend,
+                                                    typename OutOf<T>::type* __restrict__ out, float* __restrict__ stats) {
+  typedef typename OutOf<T>::type TO;                          // output element (fp8 operands produce bf16)
+  constexpr int EPPO = Elem<TO>::EPP;
   constexpr int EPP = Elem<T>::EPP;
   constexpr int BK = 8 * EPP;
   constexpr int NT = BM * 2;                                  // threads: one wave per 64 x 64 (or narrower) sub-tile
@@ -265,7 +273,15 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   // One MFMA cluster (MR x NR tiles, one k-step); `h0` / `h1` are issued in the shadow of its first / second MFMA
   // (fragment reads, LDS-DMA issue), so the matrix pipe already has work when the wave turns to them.
   auto mfma_one = [&](int buf, int i, int j) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 1) {
+      // a 16-byte fragment holds 16 e4m3 values: two MFMAs of K = 16 (any K permutation is fine, A and B share it), i.e.
+      // half the LDS fragment traffic per MAC of the bf16 form
+      const uint4 av = af[buf][i], bw = bfr[buf][j];          // (composed from the dwords: pointer arithmetic on the fragment
+      const long a0 = (long)(((unsigned long)av.y << 32) | av.x), a1 = (long)(((unsigned long)av.w << 32) | av.z);   // arrays puts them in scratch)
+      const long b0 = (long)(((unsigned long)bw.y << 32) | bw.x), b1 = (long)(((unsigned long)bw.w << 32) | bw.z);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[i][j], 0, 0, 0);
+    } else if constexpr (sizeof(T) == 2) {
 #ifdef P2PHD_ABL_NOMFMA
       asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
 #elif defined(P2PHD_ABL_MFMA16)
@@ -386,7 +402,9 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   __syncthreads();
 
   // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
-  constexpr int CROW = BN * (int)sizeof(T) + 16;            // padded C-tile row
+  constexpr int CROW = BN * (int)sizeof(TO) + 16;           // padded C-tile row
+  float oscale = 1.f;                                        // fp8: de-quantisation factor of the packed weights
+  if constexpr (sizeof(T) == 1) oscale = *d.out_scale;
   char* ct = stages;
   // the activation is chosen ONCE per tile (a per-element switch costs a dozen scalar branches per value and keeps
   // the tanh expansion in every element's path): a straight-line instance for tanh, one for the slope family
@@ -408,11 +426,12 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if constexpr (sizeof(T) == 1) acc[i][j][e] *= oscale;
           float v = acc[i][j][e] + bv;
           if (p_base + row < p_end) s1 += v;
           if constexpr (ACT == P2PHD_ACT_TANH) v = tanhf(v);
           else v = v > 0.f ? v : neg_slope * v;                // none / ReLU / LeakyReLU(0.2) as one select
-          *reinterpret_cast<T*>(ct + row * CROW + col * (int)sizeof(T)) = from_f<T>(v);
+          *reinterpret_cast<TO*>(ct + row * CROW + col * (int)sizeof(TO)) = from_f<TO>(v);
         }
       }
       if (stats != nullptr) {
@@ -448,11 +467,11 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   if (act == P2PHD_ACT_TANH) stage_tile(std::integral_constant<int, P2PHD_ACT_TANH>{});
   else stage_tile(std::integral_constant<int, P2PHD_ACT_NONE>{});
   __syncthreads();
-  constexpr int CPR = BN / EPP;                              // 16-byte pieces per C-tile row
+  constexpr int CPR = BN / EPPO;                             // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
-    int k = n0 + pc * EPP;
+    int k = n0 + pc * EPPO;
     const int2 ri = rinfo[row];
     if (ri.x < 0 || k >= n_extent) continue;
     const int nn = ri.x;
@@ -467,10 +486,10 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
     uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
     if (addend != nullptr) {
       const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * Cp_out + k);
-      T* vv = reinterpret_cast<T*>(&v);
-      const T* aa = reinterpret_cast<const T*>(&a);
+      TO* vv = reinterpret_cast<TO*>(&v);
+      const TO* aa = reinterpret_cast<const TO*>(&a);
 #pragma unroll
-      for (int e = 0; e < EPP; ++e) vv[e] = from_f<T>(to_f(vv[e]) + to_f(aa[e]));
+      for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) + to_f(aa[e]));
     }
     *reinterpret_cast<uint4*>(out + opix * Cp_out + k) = v;
   }
@@ -1138,6 +1157,42 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m
   }
 }
 
+// ---- fp8 (OCP e4m3) weight pack of a dense direct plan: wp8[row][tap][Cp] = e4m3(w * 448 / amax), scale = amax / 448 ----
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ amax_bits) {
+  float m = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[e]));
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));     // non-negative floats order like their bits
+}
+__global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale2) {
+  const float a = fmaxf(__uint_as_float(*amax_bits), 1e-30f);
+  scale2[0] = a / 448.f;                                                      // de-quantisation factor (read by the conv epilogue)
+  scale2[1] = 448.f / a;
+}
+__global__ __launch_bounds__(256) void pack_fp8_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, unsigned char* __restrict__ wp,
+                                                       int rows_pad, const float* __restrict__ scale2) {
+  // thread = (row, 4 consecutive channels of one tap): one packed dword
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK;
+  const float q = scale2[1];
+  const long total = (long)rows_pad * (KK / 4);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / (KK / 4));
+    const int kk = (int)(e - (long)row * (KK / 4)) * 4;
+    const int t = kk / Cp, c = kk - t * Cp;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (row < m.rows && t < T_taps) {
+      const int ta = t / d.ntw, tb = t - ta * d.ntw;
+      const long base = (long)row * m.s_row + (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c + i < m.inner) v[i] = w[base + (long)(c + i) * m.s_inner] * q;
+    }
+    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
+    *reinterpret_cast<int*>(wp + (size_t)row * KK + kk) = pk;
+  }
+}
+
 // reflect-pad adjoint: dx[n,i,j,:] = sum over padded positions that mirror onto (i,j) of dxp (+ addend)
 template <typename T>
 __global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restrict__ addend, T* __restrict__ dx,
@@ -1237,7 +1292,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   d.stats_slots = (d.Hg * d.Wg + MR * 32 - 1) / (MR * 32);
   if (slot_rows) *slot_rows = MR * 32;
   constexpr int STAGE = (BM + BN) * kRowBytes;
-  constexpr int CT = BM * (BN * (int)sizeof(T) + 16);
+  constexpr int CT = BM * (BN * (int)sizeof(typename OutOf<T>::type) + 16);
   const int tab = ((d.nth * d.ntw * BM * 4 + 15) & ~15) + BM * 8;        // gather table + row table
   const size_t lds = tab + (size_t)(NSTAGE * STAGE > CT ? NSTAGE * STAGE : CT);
   auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE>;
@@ -1251,7 +1306,8 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
                      d.Wg == g_probe_cfg.wg && g_probe_cfg.ev.size() < 4096;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (probe) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
-  hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const T*)addend, (T*)out, stats);
+  typedef typename OutOf<T>::type TO;
+  hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const TO*)addend, (TO*)out, stats);
   if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
 }
@@ -1278,7 +1334,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   const bool fits_huge = sizeof(T) == 2 && 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
   bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
   const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
-  const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(T) + 16) + tabb <= kLds;
+  const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(typename OutOf<T>::type) + 16) + tabb <= kLds;
   // short reductions (<= 4 K steps: the folded 2-channel layers, the 4-channel D input) are all prologue and epilogue:
   // keep the light 128-row kernel there, several of which fit on a CU and overlap each other's fixed costs
   const bool short_k = d.KK <= 4 * 8 * Elem<T>::EPP;
@@ -1289,7 +1345,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   if (force == 512) { huge = fits_huge && k > 128; }
   // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
-  if (force == 192 && sizeof(T) == 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
+  if (force == 192 && sizeof(T) <= 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if (huge && force == 0 && k % 192 == 0) {
     const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
@@ -1299,10 +1355,12 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
   // where 128-wide tiles would gather the A operand once more and pad the last tile
-  if (!huge && force == 0 && sizeof(T) == 2 && enough_px && !short_k && k % 192 == 0 && k <= 384 &&
+  if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && k <= 384 &&
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
-  if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)
+    if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  }
   if (big && bn == 128) {
     if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
     return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
@@ -1325,7 +1383,7 @@ int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, c
   if (d_in.N == 0 || d_in.Hg * d_in.Wg == 0) return P2PHD_OK;
   GDesc d = d_in;
   {
-    const size_t esz = dtype == P2PHD_BF16 ? 2 : 4;
+    const size_t esz = dtype == P2PHD_FP8_INTERNAL ? 1 : (dtype == P2PHD_BF16 ? 2 : 4);
     const size_t ib = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz;
     const size_t wb = (size_t)round_up(d.cls_cp > 0 ? 4 * d.cls_cp : d.Cp_out, 128) * d.KK * esz;   // packed rows are padded to 128
     P2PHD_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "gconv: tensor larger than 4 GiB");
@@ -1334,6 +1392,10 @@ int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, c
   }
   P2PHD_REQUIRE(d.Cp_in % 8 == 0 && d.Cp_out % 8 == 0, "gconv: channel pitch must be a multiple of 8");
   P2PHD_REQUIRE((long)d.N * d.Hin * d.Win < (1l << 31) && (long)d.N * d.Hout * d.Wout < (1l << 31), "gconv: too many pixels");
+  if (dtype == P2PHD_FP8_INTERNAL) {
+    P2PHD_REQUIRE(d.Cp_in % 16 == 0 && d.KK % 128 == 0 && d.out_scale != nullptr, "gconv(fp8): channel pitch %% 16, GEMM-K %% 128 and a scale are required");
+    return launch_gconv_t<fp8_t>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  }
   if (dtype == P2PHD_BF16) return launch_gconv_t<bf16_t>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if (dtype == P2PHD_F32) return launch_gconv_t<float>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   set_error("gconv: unsupported dtype %d", dtype);
@@ -1464,6 +1526,18 @@ int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* 
   else
     hipLaunchKernelGGL(pack_kernel<float>, grid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
   return check_launch("pack_weights");
+}
+
+int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, int rows_pad, float* scale2, unsigned* amax_bits,
+                    hipStream_t st) {
+  (void)hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
+  const long n = (long)m.rows * m.s_row;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st, w, n, amax_bits);
+  hipLaunchKernelGGL(fp8_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits, scale2);
+  const long total = (long)rows_pad * (d.KK / 4);
+  hipLaunchKernelGGL(pack_fp8_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, d, m, w,
+                     (unsigned char*)wp8, rows_pad, scale2);
+  return check_launch("pack_weights(fp8)");
 }
 
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,

@@ -391,6 +391,65 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
                             npix, slot_rows, st);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// fp8 forward (BASELINE configs[4]: "bf16 + fp8 MFMA conv weights"): OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 for
+// the wide stride-1 layers (residual trunk, discriminator 256 -> 512), fp32 master weights and the bf16 backward unchanged.
+// Weights are quantised per layer (scale = amax / 448, found on the device: no host synchronisation), activations arrive
+// already quantised (scale 1: they are InstanceNorm outputs) from p2phd_instnorm_act_fwd_q8.
+// ------------------------------------------------------------------------------------------------------
+namespace {
+bool fp8_eligible(const p2phd_conv_desc* c) {
+  return c->dtype == P2PHD_BF16 && !c->transposed && c->stride == 1 && fold_mode(c) == FOLD_NONE && c->C % 16 == 0 &&
+         (c->R * c->S * c->C) % 128 == 0;
+}
+size_t fp8_weight_bytes(const p2phd_conv_desc* c) { return align256((size_t)round_up(c->K, 128) * c->R * c->S * c->C); }
+}  // namespace
+
+extern "C" int p2phd_conv_fp8_eligible(const p2phd_conv_desc* c) { return check_desc(c) == P2PHD_OK && fp8_eligible(c) ? 1 : 0; }
+
+extern "C" size_t p2phd_conv_fp8_packed_bytes(const p2phd_conv_desc* c) {
+  if (check_desc(c) != P2PHD_OK || !fp8_eligible(c)) return 0;
+  return fp8_weight_bytes(c) + 256;                               // + {scale, 1/scale, amax bits}
+}
+
+extern "C" int p2phd_conv_fp8_pack_weights(const p2phd_conv_desc* c, const float* w, void* packed8, void* stream) {
+  if (int rc = check_desc(c)) return rc;
+  P2PHD_REQUIRE(fp8_eligible(c), "conv_fp8: layer not eligible (stride-1 Conv2d, channels %% 16, taps * channels %% 128)");
+  P2PHD_REQUIRE(w && packed8, "conv_fp8_pack_weights: null pointer");
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  Plan p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
+  p.d.KK = c->R * c->S * c->C;
+  const long RS = (long)c->R * c->S;
+  const WMap m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
+  char* tail = static_cast<char*>(packed8) + fp8_weight_bytes(c);
+  return launch_pack_fp8(p.d, m, w, packed8, p.rows_pad, reinterpret_cast<float*>(tail), reinterpret_cast<unsigned*>(tail + 16),
+                         (hipStream_t)stream);
+}
+
+extern "C" int p2phd_conv_fwd_fp8(const p2phd_conv_desc* c, const void* x8, const void* packed8, const float* bias, int act,
+                                  void* y, float* stats, void* workspace, void* stream) {
+  if (int rc = check_desc(c)) return rc;
+  P2PHD_REQUIRE(fp8_eligible(c), "conv_fwd_fp8: layer not eligible");
+  P2PHD_REQUIRE(act >= P2PHD_ACT_NONE && act <= P2PHD_ACT_RELU, "conv_fwd_fp8: bad activation %d", act);
+  P2PHD_REQUIRE(stats == nullptr || act == P2PHD_ACT_NONE, "conv_fwd_fp8: statistics are taken of the pre-activation output");
+  if (c->N == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(x8 && packed8 && y && (stats == nullptr || workspace), "conv_fwd_fp8: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  Plan p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
+  p.d.KK = c->R * c->S * c->C;
+  p.d.act = act;
+  p.d.out_scale = reinterpret_cast<const float*>(static_cast<const char*>(packed8) + fp8_weight_bytes(c));
+  float* table = static_cast<float*>(workspace);
+  int slot_rows = 0;
+  if (int rc = launch_gconv(p.d, P2PHD_FP8_INTERNAL, x8, packed8, bias, nullptr, y, stats ? table : nullptr, st, &slot_rows)) return rc;
+  if (stats == nullptr) return P2PHD_OK;
+  const long npix = (long)p.d.Hg * p.d.Wg;
+  return launch_stats_merge(table, stats, c->N, (int)((npix + slot_rows - 1) / slot_rows), 1, cpitch(c->K), c->K, npix, slot_rows, st);
+}
+
 extern "C" size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
   int Ho, Wo;

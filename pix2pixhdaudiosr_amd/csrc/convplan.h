@@ -20,6 +20,7 @@ struct GDesc {
   int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
   int stats_slots;                            // slots per sample of the statistics table (set by the launcher)
+  const float* out_scale;                     // fp8 operands: device pointer to the weights' de-quantisation factor
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -36,6 +37,11 @@ struct WMap {
 inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
   return WMap{rows, inner, s_row, s_inner, rows > 0 ? rows : 1, 0, inner > 0 ? inner : 1, 0, S};
 }
+
+// operand type code of the fp8 forward launches (not part of the public dtype enum: activations stay bf16 at the ABI)
+constexpr int P2PHD_FP8_INTERNAL = 2;
+int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, int rows_pad, float* scale2, unsigned* amax_bits,
+                    hipStream_t st);
 
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;

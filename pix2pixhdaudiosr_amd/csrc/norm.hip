@@ -52,10 +52,12 @@ struct ChanConsts {
 };
 
 // ---- forward: out = act((y - mean) * rstd) + residual --------------------------------------------
+// out8 (optional, bf16 instantiation only): the same values as OCP e4m3 (scale 1, saturated at +-448), the operand of the
+// next layer's fp8 forward conv (p2phd_conv_fwd_fp8)
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y, const float* __restrict__ stats,
                                                          const T* __restrict__ residual, T* __restrict__ out, long HW,
-                                                         int C, int Cp, float eps, int act) {
+                                                         int C, int Cp, float eps, int act, unsigned char* __restrict__ out8) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int UN = 4;
   const int n = blockIdx.y;
@@ -85,13 +87,25 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
       const T* rr = reinterpret_cast<const T*>(&rv[u]);
       uint4 ov;
       T* oo = reinterpret_cast<T*>(&ov);
+      float fq[EPP];
 #pragma unroll
       for (int k = 0; k < EPP; ++k) {
         float f = act_fwd((to_f(vv[k]) - cc.mean[k]) * cc.rstd[k], nslope);
         if (residual != nullptr) f += to_f(rr[k]);
-        oo[k] = from_f<T>(pc * EPP + k < C ? f : 0.f);
+        f = pc * EPP + k < C ? f : 0.f;
+        oo[k] = from_f<T>(f);
+        fq[k] = fminf(fmaxf(f, -448.f), 448.f);
       }
       if (e < total) *reinterpret_cast<uint4*>(out + base + (size_t)e * EPP) = ov;
+      if constexpr (EPP == 8) {
+        if (out8 != nullptr && e < total) {                      // uniform
+          int lo = __builtin_amdgcn_cvt_pk_fp8_f32(fq[0], fq[1], 0, false);
+          lo = __builtin_amdgcn_cvt_pk_fp8_f32(fq[2], fq[3], lo, true);
+          int hi = __builtin_amdgcn_cvt_pk_fp8_f32(fq[4], fq[5], 0, false);
+          hi = __builtin_amdgcn_cvt_pk_fp8_f32(fq[6], fq[7], hi, true);
+          *reinterpret_cast<int2*>(out8 + base + (size_t)e * EPP) = make_int2(lo, hi);
+        }
+      }
     }
   }
 }
@@ -647,20 +661,32 @@ int launch_plane_stats(int dtype, const void* y, float* stats, float* scratch, i
 }
 }  // namespace p2phd
 
-extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
-                                      int N, int64_t HW, int C, float eps, int act, void* stream) {
+static int instnorm_act_fwd_impl(int dtype, const void* y, const float* stats, const void* residual, void* out, void* out8,
+                                 int N, int64_t HW, int C, float eps, int act, void* stream) {
   const int Cp = (C + 7) & ~7;
   P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
   if (N == 0 || HW == 0) return P2PHD_OK;
   P2PHD_REQUIRE(y && stats && out, "instnorm_act_fwd: null pointer");
+  P2PHD_REQUIRE(out8 == nullptr || dtype == P2PHD_BF16, "instnorm_act_fwd_q8: the fp8 twin goes with bf16 activations");
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, stats, (const bf16_t*)residual, (bf16_t*)out, (long)HW, C, Cp, eps, act),
-             hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)y, stats, (const float*)residual, (float*)out, (long)HW, C, Cp, eps, act),
+             hipLaunchKernelGGL(in_act_fwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, stats, (const bf16_t*)residual, (bf16_t*)out, (long)HW, C, Cp, eps, act, (unsigned char*)out8),
+             hipLaunchKernelGGL(in_act_fwd_kernel<float>, grid, dim3(256), 0, st, (const float*)y, stats, (const float*)residual, (float*)out, (long)HW, C, Cp, eps, act, (unsigned char*)nullptr),
              "instnorm_act_fwd");
   return p2phd::check_launch("instnorm_act_fwd");
+}
+
+extern "C" int p2phd_instnorm_act_fwd(int dtype, const void* y, const float* stats, const void* residual, void* out,
+                                      int N, int64_t HW, int C, float eps, int act, void* stream) {
+  return instnorm_act_fwd_impl(dtype, y, stats, residual, out, nullptr, N, HW, C, eps, act, stream);
+}
+
+extern "C" int p2phd_instnorm_act_fwd_q8(int dtype, const void* y, const float* stats, const void* residual, void* out, void* out8,
+                                         int N, int64_t HW, int C, float eps, int act, void* stream) {
+  P2PHD_REQUIRE(out8 != nullptr, "instnorm_act_fwd_q8: null fp8 output");
+  return instnorm_act_fwd_impl(dtype, y, stats, residual, out, out8, N, HW, C, eps, act, stream);
 }
 
 static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,

@@ -171,6 +171,36 @@ def _compile(seq):
     return steps
 
 
+def _flat_conv_steps(steps):
+    out = []
+    for s in steps:
+        if isinstance(s, _ResStep):
+            out += [s.a, s.b]
+        else:
+            out.append(s)
+    return out
+
+
+def enable_fp8(net, min_channels=256):
+    """BASELINE configs[4] ("bf16 + fp8 MFMA conv weights"): run the forward of the wide stride-1 convs (residual trunk,
+    discriminator 256 -> 512) on OCP e4m3 operands.  A layer qualifies when its input comes straight out of an InstanceNorm
+    pass of this network (which then also writes the e4m3 twin, scale 1), it has >= `min_channels` input channels and the
+    kernel's shape constraints hold.  fp32 master weights, bf16 activations and the whole backward pass are unchanged.
+    Returns the number of layers switched."""
+    n = 0
+    names = [k for k in net._modules if isinstance(getattr(net, k), nn.Sequential)]
+    for name in names:
+        convs = _flat_conv_steps(net._steps(name))
+        for prev, cur in zip(convs[:-1], convs[1:]):
+            sp = cur.spec
+            ok = (prev.spec.norm and not sp.transposed and sp.stride == 1 and sp.cin >= min_channels and sp.cin % 16 == 0
+                  and (sp.k * sp.k * sp.cin) % 128 == 0 and sp.cin > 4 and sp.cout > 4)
+            if ok:
+                sp.fp8, prev.spec.emit_q8 = True, True
+                n += 1
+    return n
+
+
 def _run(steps, x, residual_last=None, cuts=None, cut_after=()):
     """Run fused steps in order.  `cuts` (a list) collects the output of every step whose index is in `cut_after`: the
     points where the staged backward of the data-parallel step hands over (Pix2PixHDModel._phase_a)."""

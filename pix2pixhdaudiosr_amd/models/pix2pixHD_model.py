@@ -112,6 +112,14 @@ class Pix2PixHDModel(BaseModel):
             self.netD = networks.define_D(input_nc + opt.output_nc, opt.ndf, opt.n_layers_D, opt.norm, False, opt.num_D,
                                           not opt.no_ganFeat_loss, gpu_ids=self.gpu_ids, dtype=self.compute_dtype,
                                           verbose=verbose)
+        # opt.fp8: e4m3 forward of the wide layers on top of bf16 compute (BASELINE configs[4])
+        self.fp8_layers = 0
+        if _opt(opt, 'fp8', False):
+            if self.compute_dtype != torch.bfloat16:
+                raise NotImplementedError("--fp8 needs bf16 compute (--fp16)")
+            self.fp8_layers = networks.enable_fp8(self.netG)
+            if self.isTrain:
+                self.fp8_layers += networks.enable_fp8(self.netD)
         if verbose:
             print('---------- Networks initialized -------------')
 

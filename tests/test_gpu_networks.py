@@ -84,3 +84,39 @@ def test_gan_loss_kat(golden_networks):
     pred = [[torch.from_numpy(g["ganloss_p0"]).cuda()], [torch.from_numpy(g["ganloss_p1"]).cuda()]]
     assert abs(float(crit(pred, True)) - float(g["ganloss_real"])) < 1e-5
     assert abs(float(crit(pred, False)) - float(g["ganloss_fake"])) < 1e-5
+
+
+def test_fp8_forward_of_wide_layers():
+    """BASELINE configs[4]: e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8) for the forward of the wide stride-1 convs, bf16
+    everywhere else, fp32 master weights.  Stated tolerance: a 256-channel generator (the trunk runs fp8) stays within
+    6e-2 relative L2 of its bf16 self on outputs and 0.97 cosine on the trunk weight gradients (the backward is bf16 on
+    bf16 activations either way; only the forward values it starts from differ)."""
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    torch.manual_seed(3)
+    ref = PN.define_G(2, 2, 64, "global", 2, 3, 0, 0, "instance", [], dtype=torch.bfloat16, verbose=False).cuda()
+    q = PN.define_G(2, 2, 64, "global", 2, 3, 0, 0, "instance", [], dtype=torch.bfloat16, verbose=False).cuda()
+    q.load_state_dict(ref.state_dict())
+    x = torch.rand(2, 2, 64, 32, generator=torch.Generator().manual_seed(1)).cuda()
+    ref(x)                                                           # compile the steps
+    q(x)
+    n = PN.enable_fp8(q)
+    assert n == 6                                                    # the six 3x3 convs of the three 256-channel ResnetBlocks
+    cot = torch.randn(2, 2, 64, 32, generator=torch.Generator().manual_seed(2)).cuda()
+    ya = ref(x); yb = q(x)
+    assert rel_err(yb.detach().cpu().numpy(), ya.detach().cpu().numpy()) < 6e-2
+    ga = torch.autograd.grad((ya * cot).sum(), list(ref.parameters()))
+    gb = torch.autograd.grad((yb * cot).sum(), list(q.parameters()))
+    names = [k for k, _ in ref.named_parameters()]
+    worst = min(cosine(b.cpu().numpy(), a.cpu().numpy()) for k, a, b in zip(names, ga, gb) if k.endswith(".weight"))
+    assert worst > 0.97, worst
+    # a fp8 layer really ran on the fp8 entry point: its packed e4m3 weights exist and decode back to the master weights
+    sp = [s for s in PN._flat_conv_steps(q._steps('model')) if s.spec.fp8][0]
+    buf = sp.spec._packed[("fp8", 1)][1]
+    w = sp.conv.weight.detach()
+    K, Cc = w.shape[0], w.shape[1]
+    scale = buf[-256:-252].view(torch.float32).item() if False else buf[buf.numel() - 256:buf.numel() - 252].view(torch.float32).item()
+    assert abs(scale - float(w.abs().max()) / 448.0) < 1e-6 * max(scale, 1e-12) + 1e-12
+    codes = buf[: 128 * 9 * Cc].view(128, 9, Cc)[:K]                 # [row][tap][channel] e4m3 bytes
+    dec = codes.view(torch.float8_e4m3fn).float() * scale
+    want = w.permute(0, 2, 3, 1).reshape(K, 9, Cc)
+    assert rel_err(dec.cpu().numpy(), want.cpu().numpy()) < 4e-2     # 3 mantissa bits: ~2.5 % rms
