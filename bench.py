@@ -29,7 +29,7 @@ M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd
 M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
 
 
-def make_opt(batch, dtype_bf16=True):
+def make_opt(batch, dtype_bf16=True, fp8=False):
     return SimpleNamespace(
         gpu_ids=[0], isTrain=True, checkpoints_dir="/tmp/p2phd_bench", name="bench", model="pix2pixHD",
         input_nc=2, output_nc=2, label_nc=0, hr_sampling_rate=48000, lr_sampling_rate=8000,
@@ -39,7 +39,7 @@ def make_opt(batch, dtype_bf16=True):
         use_hifigan_D=False, use_time_D=False, verbose=False, continue_train=False, load_pretrain="",
         which_epoch="latest", pool_size=0, lr=0.0002, beta1=0.5, no_vgg_loss=True, use_match_loss=False,
         niter_fix_global=0, explicit_encoding=True, alpha=0.6, min_value=1e-7, mask=True, mask_mode="mode2",
-        lambda_feat=10.0, fp16=dtype_bf16, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
+        lambda_feat=10.0, fp16=dtype_bf16, fp8=fp8, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
 
 
 def time_trunk_conv(batch, iters=20):
@@ -187,6 +187,8 @@ def main():
     ap.add_argument("--allow-eager-fallback", action="store_true",
                     help="keep measuring with the eager step if graph capture / replay fails (default: exit non-zero)")
     ap.add_argument("--no-mdct", action="store_true", help="skip the stand-alone MDCT4 / IMDCT4 measurement")
+    ap.add_argument("--fp8", action="store_true",
+                    help="variant of BASELINE configs[4]: e4m3 forward of the wide stride-1 convs on top of bf16 (NOT the headline dtype)")
     a = ap.parse_args()
 
     if a.gpus < 1:
@@ -216,7 +218,7 @@ def main():
     from pix2pixhdaudiosr_amd import parallel_state
 
     torch.manual_seed(1234)                      # same initial weights on every rank (reference default seed)
-    opt = make_opt(a.batch)
+    opt = make_opt(a.batch, fp8=a.fp8)
     opt.gpu_ids = [local]
     model = create_model(opt)
     if world > 1:
@@ -301,7 +303,7 @@ def main():
             "metric": "MDCT spectrogram frames/sec (G+D fwd+bwd) at 512x256",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16+fp8(e4m3 forward of the wide convs)" if a.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "configs[1]: ngf=48 n_local_enhancers=0 (GlobalGenerator nd4 nb9) + MultiscaleDiscriminator "
                                    "num_D=2, 512x256 MDCT4 (n_fft 1024, hop 512), LSGAN + feature matching, Adam, bf16 MFMA",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
