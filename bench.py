@@ -314,6 +314,11 @@ def main():
                                            "D(fake) forward executes ~3.5 % fewer"},
             "per_rank_ms_per_step": rank_ms,
         }
+        if a.fp8:
+            from pix2pixhdaudiosr_amd import _ops as _o
+            out["fp8"] = {"layers_switched": model.fp8_layers, "fp8_conv_launches_recorded_by_the_host": _o._FP8_CALLS[0],
+                          "what": "OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 for the forward of the stride-1 convs with >= 256 "
+                                  "input channels; fp32 master weights, bf16 activations and the bf16 backward unchanged"}
         if dist_info is not None:
             out["dist"] = dist_info
         if graph_error is not None:

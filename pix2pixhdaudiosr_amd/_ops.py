@@ -95,6 +95,8 @@ def _check_arena(ctx, device):
 _KERNEL_PROBE = {"match": None, "events": []}
 # debugging hook: when a list, every conv block's backward appends (spec, g, dy, gx) clones (tools only)
 _BWD_TRACE = [None]
+# number of forward convs that ran on the fp8 entry point (bench.py reports it with --fp8)
+_FP8_CALLS = [0]
 
 
 # parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
@@ -379,6 +381,7 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             e0 = None
         if x8 is not None:
+            _FP8_CALLS[0] += 1
             check(L.p2phd_conv_fwd_fp8(C.byref(d), ptr(x8), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd_fp8")
         else:
             check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")

@@ -1159,10 +1159,24 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m
 
 // ---- fp8 (OCP e4m3) weight pack of a dense direct plan: wp8[row][tap][Cp] = e4m3(w * 448 / amax), scale = amax / 448 ----
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ w, long n, unsigned* __restrict__ amax_bits) {
+  // float4 pieces, four in flight per thread (n is a multiple of 4 and w 16-byte aligned: flat Adam buffer slices)
   float m = 0.f;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) m = fmaxf(m, fabsf(w[e]));
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  const float4* w4 = reinterpret_cast<const float4*>(w);
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < n4; e0 += 4 * stride) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = w4[min(e0 + u * stride, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+  }
+  for (long e = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) m = fmaxf(m, fabsf(w[e]));
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(amax_bits, __float_as_uint(m));     // non-negative floats order like their bits
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(amax_bits, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));   // non-negative floats order like their bits
 }
 __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* __restrict__ scale2) {
   const float a = fmaxf(__uint_as_float(*amax_bits), 1e-30f);
@@ -1171,25 +1185,33 @@ __global__ void fp8_scale_kernel(const unsigned* __restrict__ amax_bits, float* 
 }
 __global__ __launch_bounds__(256) void pack_fp8_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, unsigned char* __restrict__ wp,
                                                        int rows_pad, const float* __restrict__ scale2) {
-  // thread = (row, 4 consecutive channels of one tap): one packed dword
+  // thread = (row, 4 consecutive channels): reads their 4 x T_taps master values (one contiguous run, consecutive threads
+  // continue it), writes one packed dword per tap (consecutive threads -> consecutive dwords of the [tap][channel] row)
   const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK;
   const float q = scale2[1];
-  const long total = (long)rows_pad * (KK / 4);
+  const int c4n = Cp / 4;
+  const long total = (long)rows_pad * c4n;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int row = (int)(e / (KK / 4));
-    const int kk = (int)(e - (long)row * (KK / 4)) * 4;
-    const int t = kk / Cp, c = kk - t * Cp;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row < m.rows && t < T_taps) {
-      const int ta = t / d.ntw, tb = t - ta * d.ntw;
-      const long base = (long)row * m.s_row + (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+    const int row = (int)(e / c4n), c = (int)(e - (long)row * c4n) * 4;
+    const bool row_ok = row < m.rows;
+    const float* src = w + (row_ok ? (long)row * m.s_row : 0) + (long)min(c, max(m.inner - 4, 0)) * T_taps;
+    for (int t0 = 0; t0 < T_taps; t0 += 4) {
+      float v[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
-        if (c + i < m.inner) v[i] = w[base + (long)(c + i) * m.s_inner] * q;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[i][u] = src[i * T_taps + min(t0 + u, T_taps - 1)];       // unconditional, clamped
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (t0 + u >= T_taps) break;
+        float f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = (row_ok && c + i < m.inner) ? v[i][u] * q : 0.f;
+        int pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+        pk = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], pk, true);
+        *reinterpret_cast<int*>(wp + (size_t)row * KK + (size_t)(t0 + u) * Cp + c) = pk;
+      }
     }
-    int pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], 0, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], pk, true);
-    *reinterpret_cast<int*>(wp + (size_t)row * KK + kk) = pk;
   }
 }
 
@@ -1347,10 +1369,12 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
   if (force == 192 && sizeof(T) <= 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
-  if (huge && force == 0 && k % 192 == 0) {
+  // (fp8 operands: no 256 x 256 instantiation -- it spills -- so the 192-wide tile is taken whenever it divides the output)
+  const bool wide = enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
+  if ((huge || (sizeof(T) == 1 && wide)) && force == 0 && k % 192 == 0) {
     const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
     const double c256 = std::ceil(wg256 / 256.0) * 256.0 * 256.0, c192 = std::ceil(wg192 / 256.0) * 256.0 * 192.0 / 0.95;
-    if (c192 < c256 && 2 * 448 * kRowBytes + tabb <= kLds)
+    if ((sizeof(T) == 1 || c192 < c256) && 2 * 448 * kRowBytes + tabb <= kLds)
       return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
@@ -1532,9 +1556,9 @@ int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, in
                     hipStream_t st) {
   (void)hipMemsetAsync(amax_bits, 0, sizeof(unsigned), st);
   const long n = (long)m.rows * m.s_row;
-  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::min<long>((n + 255) / 256, 1024)), dim3(256), 0, st, w, n, amax_bits);
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)std::max<long>(1, std::min<long>((n / 4 + 1023) / 1024, 2048))), dim3(256), 0, st, w, n, amax_bits);
   hipLaunchKernelGGL(fp8_scale_kernel, dim3(1), dim3(1), 0, st, amax_bits, scale2);
-  const long total = (long)rows_pad * (d.KK / 4);
+  const long total = (long)rows_pad * (d.Cp_in / 4);
   hipLaunchKernelGGL(pack_fp8_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 8192)), dim3(256), 0, st, d, m, w,
                      (unsigned char*)wp8, rows_pad, scale2);
   return check_launch("pack_weights(fp8)");
