@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FRAMES = 256                      # spectrogram frames per sample at 512x256
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # same guide: ~5 PF dense fp8
 M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd4 nb9 @512x256 (SURVEY 8a probe)
 M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
 
@@ -365,6 +366,12 @@ def main():
                            "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                            "kernel": "gconv_kernel<bf16> implicit-GEMM Conv3x3 768->768 @32x16 (residual trunk, 18 of 28 generator convs)",
                            "launch_us": sec * 1e6, "flops_per_launch": flops}
+        if a.fp8 and world == 1:
+            # the probed launches are the e4m3 forward of the trunk: price them against the dense fp8 peak, and the
+            # recorded HBM traffic (taken on the bf16 kernel) does not apply
+            out["roofline"].update({"peak": FP8_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / FP8_DENSE_PEAK_TFLOPS,
+                                    "traffic": None, "traffic_source": None,
+                                    "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
         if world == 1 and not a.no_mdct:
             out["mdct"] = time_mdct(a.batch)
             log("mdct alone: " + ", ".join(f"{k} {v['us']:.1f} us {v['GB_per_s']:.0f} GB/s" for k, v in out["mdct"].items()))

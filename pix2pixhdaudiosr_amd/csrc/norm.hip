@@ -235,16 +235,19 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
 // One launch instead of memset + reduce + apply: a workgroup owns sample n and 128 bytes of channels (8 pieces); its
 // 256 threads are 8 piece columns x 32 pixel slices and keep their g and y pieces IN REGISTERS between the reduction
 // and the apply step, so both tensors are read from HBM exactly once (3 tensor passes instead of 5).
-template <typename T, int ITERS>
+template <typename T, int ITERS, int CGN>
 __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                const float* __restrict__ stats, T* __restrict__ dy, int HW,
                                                                int C, int Cp, float eps, int act, float* __restrict__ db) {
   constexpr int EPP = Elem<T>::EPP;
-  __shared__ float s_red[4][8][2 * EPP];
-  __shared__ float s_tot[8][2 * EPP];
-  const int tid = threadIdx.x, cg = tid & 7, sl = tid >> 3, wave = tid >> 6;
+  // CGN piece columns x (256 / CGN) pixel slices per workgroup: CGN = 4 doubles the workgroups of a 64-channel block and
+  // halves the registers a thread holds (the 8-column form ran 1.5 workgroups per CU on the trunk: latency-bound)
+  constexpr int NSL = 256 / CGN;
+  __shared__ float s_red[4][CGN][2 * EPP];
+  __shared__ float s_tot[CGN][2 * EPP];
+  const int tid = threadIdx.x, cg = tid & (CGN - 1), sl = tid / CGN, wave = tid >> 6;
   const int n = blockIdx.y, cpr = Cp / EPP;
-  const int pc = blockIdx.x * 8 + cg;
+  const int pc = blockIdx.x * CGN + cg;
   const bool col_ok = pc < cpr;
   const size_t base = (size_t)n * HW * Cp + (size_t)(col_ok ? pc : 0) * EPP;
   const float nslope = neg_slope_of(act);
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
   uint4 gv[ITERS], yv[ITERS];
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int p = min(sl + 32 * it, HW - 1);
+    const int p = min(sl + NSL * it, HW - 1);
     gv[it] = *reinterpret_cast<const uint4*>(g + base + (size_t)p * Cp);
     yv[it] = *reinterpret_cast<const uint4*>(y + base + (size_t)p * Cp);
   }
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
   for (int k = 0; k < 2 * EPP; ++k) a[k] = 0.f;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const float live = (col_ok && sl + 32 * it < HW) ? 1.f : 0.f;
+    const float live = (col_ok && sl + NSL * it < HW) ? 1.f : 0.f;
     const T* gg = reinterpret_cast<const T*>(&gv[it]);
     const T* yy = reinterpret_cast<const T*>(&yv[it]);
 #pragma unroll
@@ -274,19 +277,18 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
       a[k] += gp; a[EPP + k] += gp * yh;
     }
   }
-  // slices of one piece column sit 8 lanes apart: reduce over lane bits 3..5, then over the 4 waves through LDS
+  // slices of one piece column sit CGN lanes apart: reduce over the upper lane bits, then over the 4 waves through LDS
 #pragma unroll
   for (int k = 0; k < 2 * EPP; ++k) {
-    a[k] += __shfl_xor(a[k], 8);
-    a[k] += __shfl_xor(a[k], 16);
-    a[k] += __shfl_xor(a[k], 32);
+#pragma unroll
+    for (int o = CGN; o < 64; o <<= 1) a[k] += __shfl_xor(a[k], o);
   }
-  if ((tid & 63) < 8) {
+  if ((tid & 63) < CGN) {
 #pragma unroll
     for (int k = 0; k < 2 * EPP; ++k) s_red[wave][cg][k] = a[k];
   }
   __syncthreads();
-  if (tid < 8 * 2 * EPP) {
+  if (tid < CGN * 2 * EPP) {
     const int c8 = tid / (2 * EPP), k = tid % (2 * EPP);
     s_tot[c8][k] = s_red[0][c8][k] + s_red[1][c8][k] + s_red[2][c8][k] + s_red[3][c8][k];
   }
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
   for (int k = 0; k < EPP; ++k) { m1[k] = s_tot[cg][k] * inv; m2[k] = s_tot[cg][EPP + k] * inv; bsum[k] = 0.f; }
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int p = sl + 32 * it;
+    const int p = sl + NSL * it;
     if (col_ok && p < HW) {
       const T* gg = reinterpret_cast<const T*>(&gv[it]);
       const T* yy = reinterpret_cast<const T*>(&yv[it]);
@@ -317,18 +319,17 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < EPP; ++k) {
-      bsum[k] += __shfl_xor(bsum[k], 8);
-      bsum[k] += __shfl_xor(bsum[k], 16);
-      bsum[k] += __shfl_xor(bsum[k], 32);
+#pragma unroll
+      for (int o = CGN; o < 64; o <<= 1) bsum[k] += __shfl_xor(bsum[k], o);
     }
-    if ((tid & 63) < 8) {
+    if ((tid & 63) < CGN) {
 #pragma unroll
       for (int k = 0; k < EPP; ++k) s_red[wave][cg][k] = bsum[k];
     }
     __syncthreads();
-    if (tid < 8 * EPP) {
+    if (tid < CGN * EPP) {
       const int c8 = tid / EPP, k = tid % EPP;
-      const int c = (blockIdx.x * 8 + c8) * EPP + k;
+      const int c = (blockIdx.x * CGN + c8) * EPP + k;
       if (c < C) atomicAdd(&db[c], s_red[0][c8][k] + s_red[1][c8][k] + s_red[2][c8][k] + s_red[3][c8][k]);
     }
   }
@@ -698,13 +699,14 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   hipStream_t st = (hipStream_t)stream;
   if (db != nullptr && !db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
-  // small planes with enough (sample, channel block) pairs to fill the chip: single-launch register-resident variant
-  const int cblocks = (Cp / epp + 7) / 8;
-  if (HW <= 640 && (long)N * cblocks >= 128) {
-    dim3 fgrid((unsigned)cblocks, (unsigned)N);
-#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db)
-    if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 16); else P2PHD_FUSED_BWD(bf16_t, 20); }
-    else if (dtype == P2PHD_F32) { if (HW <= 512) P2PHD_FUSED_BWD(float, 16); else P2PHD_FUSED_BWD(float, 20); }
+  // small planes with enough (sample, channel block) pairs to fill the chip: single-launch register-resident variant;
+  // 4 piece columns x 64 slices per workgroup when that still leaves <= 10 iterations (planes <= 640 pixels)
+  const int cblocks4 = (Cp / epp + 3) / 4;
+  if (HW <= 640 && (long)N * cblocks4 >= 128) {
+    dim3 fgrid((unsigned)cblocks4, (unsigned)N);
+#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db)
+    if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 8); else P2PHD_FUSED_BWD(bf16_t, 10); }
+    else if (dtype == P2PHD_F32) { if (HW <= 512) P2PHD_FUSED_BWD(float, 8); else P2PHD_FUSED_BWD(float, 10); }
     else { p2phd::set_error("instnorm_act_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
 #undef P2PHD_FUSED_BWD
     return p2phd::check_launch("instnorm_act_bwd(fused)");

@@ -188,9 +188,12 @@ def enable_fp8(net, min_channels=256):
     kernel's shape constraints hold.  fp32 master weights, bf16 activations and the whole backward pass are unchanged.
     Returns the number of layers switched."""
     n = 0
-    names = [k for k in net._modules if isinstance(getattr(net, k), nn.Sequential)]
-    for name in names:
-        convs = _flat_conv_steps(net._steps(name))
+    if hasattr(net, '_scale_steps'):     # discriminator: one chain per scale (each stage is its own Sequential with getIntermFeat)
+        chains = [[s for stage in net._scale_steps(d) for s in stage] for d in range(net.num_D)]
+    else:
+        chains = [net._steps(k) for k in net._modules if isinstance(getattr(net, k), nn.Sequential)]
+    for chain in chains:
+        convs = _flat_conv_steps(chain)
         for prev, cur in zip(convs[:-1], convs[1:]):
             sp = cur.spec
             ok = (prev.spec.norm and not sp.transposed and sp.stride == 1 and sp.cin >= min_channels and sp.cin % 16 == 0
