@@ -75,7 +75,7 @@ def time_graphed(call, iters=20):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        graph.capture_begin()
+        graph.capture_begin(capture_error_mode="thread_local")   # see Pix2PixHDModel.train_step_graphed
         for _ in range(iters):
             call()
         graph.capture_end()
@@ -209,7 +209,16 @@ def main():
     if "P2PHD_FORCE_DEVICE" in os.environ:
         local = int(os.environ["P2PHD_FORCE_DEVICE"])
     torch.cuda.set_device(local)
-    if world > 1:
+    # P2PHD_REHEARSE_RCCL=1 (one rank, never set by the driver): a one-rank RCCL group with the collectives forced on, so
+    # that the exact call sequence of the N-rank step -- bucketed all-reduces between graph replays, waits, Adam --
+    # runs against real RCCL on a one-GPU box
+    rehearse = world == 1 and os.environ.get("P2PHD_REHEARSE_RCCL") == "1"
+    dist_on = world > 1 or rehearse
+    if rehearse:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
+    elif world > 1:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -222,15 +231,17 @@ def main():
     opt = make_opt(a.batch, fp8=a.fp8)
     opt.gpu_ids = [local]
     model = create_model(opt)
-    if world > 1:
-        parallel_state.enable_data_parallel(model, world)
+    if rehearse:
+        opt.grad_buckets = 4
+    if dist_on:
+        parallel_state.enable_data_parallel(model, world, force_collectives=rehearse)
     T = (FRAMES - 1) * opt.hop_length
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     hr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
     lr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -284,7 +295,7 @@ def main():
     dt = time.perf_counter() - t0
     rank_ms = [dt / a.steps * 1e3]
     dist_info = None
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
@@ -292,7 +303,8 @@ def main():
         rank_ms = [float(v.item()) / a.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+        dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rehearsal_one_rank": rehearse,
+                     "g_gradient_buckets": [int(b - a) for a, b in model.optimizer_G.bucket_log],
                      "devices": sorted({local}) if "P2PHD_FORCE_DEVICE" in os.environ else list(range(world))}
 
     if rank == 0:
@@ -379,7 +391,7 @@ def main():
             log("cpu baseline (oracle, batch 2, 4 steps) ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         torch.distributed.barrier()                               # rank 0 is still measuring its dominant kernel
         torch.distributed.destroy_process_group()
 

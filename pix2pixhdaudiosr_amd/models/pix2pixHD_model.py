@@ -407,8 +407,8 @@ class Pix2PixHDModel(BaseModel):
     # the same step captured once into HIP graphs and replayed: ~10^3 launches and the whole autograd walk cost no
     # host time afterwards, so the step rate no longer depends on the host core that feeds the GPU.  Graphs on one
     # memory pool -- A0: forward + first stage of the G backward, A1..: its further stages (one per gradient bucket),
-    # B: D backward, C: both Adam updates -- so that with data parallelism the RCCL all-reduces run BETWEEN replays,
-    # outside capture: bucket i's exchange beside stage i+1, the last G bucket and the rest beside graph B.
+    # B: D backward, Cg / Cd: the two Adam updates -- so that with data parallelism the RCCL all-reduces run BETWEEN replays,
+    # outside capture: bucket i's exchange beside stage i+1, the last G bucket beside graph B, the D exchange beside Cg.
     # ------------------------------------------------------------------------------------------
     def train_step_graphed(self, lr_audio, hr_audio):
         """`train_step` through captured graphs.  Inputs are copied into static buffers; the returned loss tensors are
@@ -435,15 +435,19 @@ class Pix2PixHDModel(BaseModel):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             gA, ranges = [], []
+            # thread-local capture mode: the RCCL watchdog thread of torch.distributed polls the events of the collectives
+            # of the eager steps (hipEventQuery) while this thread captures; in the default global mode that query is
+            # "not permitted when stream is capturing" and the watchdog takes the process down
+            mode = "thread_local"
             with torch.cuda.stream(side):
                 g0 = torch.cuda.CUDAGraph()
-                g0.capture_begin()
+                g0.capture_begin(capture_error_mode=mode)
                 st['out'] = self._phase_a_forward(st['lr'], st['hr'])
                 stages = self._g_stages()
                 for i, (run, rng) in enumerate(stages):
                     if i > 0:
                         g = torch.cuda.CUDAGraph()
-                        g.capture_begin(pool=g0.pool())
+                        g.capture_begin(pool=g0.pool(), capture_error_mode=mode)
                     else:
                         g = g0
                     run()
@@ -451,28 +455,31 @@ class Pix2PixHDModel(BaseModel):
                     gA.append(g)
                     ranges.append(rng)
                 self._loss_G = None
-                gB, gC = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                gB.capture_begin(pool=g0.pool())
+                gB, gCg, gCd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                gB.capture_begin(pool=g0.pool(), capture_error_mode=mode)
                 self._phase_b()
                 gB.capture_end()
-                gC.capture_begin(pool=g0.pool())
+                gCg.capture_begin(pool=g0.pool(), capture_error_mode=mode)
                 optG.step_local()
+                gCg.capture_end()
+                gCd.capture_begin(pool=g0.pool(), capture_error_mode=mode)
                 optD.step_local()
-                gC.capture_end()
+                gCd.capture_end()
             torch.cuda.current_stream().wait_stream(side)
             optG.step_count -= 1                                   # capture records, it does not execute
             optD.step_count -= 1
-            st['graphs'] = (gA, ranges, gB, gC)
-        gA, ranges, gB, gC = st['graphs']
+            st['graphs'] = (gA, ranges, gB, gCg, gCd)
+        gA, ranges, gB, gCg, gCd = st['graphs']
         optG.bucket_log, optD.bucket_log = [], []
         for g, (a, b) in zip(gA, ranges):
             g.replay()
             optG.reduce_range_async(a, b)                           # no-ops on one GPU
         gB.replay()
-        optD.reduce_gradients_async()
+        optD.reduce_gradients_async()                               # the D exchange runs beside the generator's Adam
         optG.wait_gradients()
+        gCg.replay()
         optD.wait_gradients()
-        gC.replay()
+        gCd.replay()
         optG.step_count += 1
         optD.step_count += 1
         # the replayed Adam changed the master weights behind the host's back: packed copies cached by ConvSpec are stale

@@ -46,6 +46,7 @@ class FlatAdam(torch.optim.Optimizer):
         self._lr_pushed = None
         self.process_group = process_group
         self.world_size = 1
+        self._collectives = False
         self._pending = None
         self.bucket_log = []
         _ops.bump_weight_epoch()
@@ -65,9 +66,12 @@ class FlatAdam(torch.optim.Optimizer):
         self._install_grad_views()
 
     # ---- data parallel: one summing all-reduce of the whole gradient buffer over RCCL ----
-    def enable_data_parallel(self, world_size, process_group=None):
+    def enable_data_parallel(self, world_size, process_group=None, force_collectives=False):
+        """`force_collectives`: issue the all-reduces even with one rank (rehearsal of the RCCL call sequence on a
+        one-GPU box: same launches, streams and waits as N ranks; the sum over one rank is the identity)."""
         self.world_size = int(world_size)
         self.process_group = process_group
+        self._collectives = self.world_size > 1 or bool(force_collectives)
 
     def param_offset(self, index):
         """Element offset inside the flat buffers of parameter `index` (construction order)."""
@@ -76,7 +80,7 @@ class FlatAdam(torch.optim.Optimizer):
     def reduce_range_async(self, start, stop):
         """Start the summing all-reduce of flat_g[start:stop] (one bucket of a staged backward).  Buckets must not
         overlap; the launches are recorded in `bucket_log` (tests assert order and coverage)."""
-        if self.world_size > 1 and stop > start:
+        if self._collectives and stop > start:
             from .parallel_state import all_reduce_flat_async
             if self._pending is None:
                 self._pending = []
@@ -85,7 +89,7 @@ class FlatAdam(torch.optim.Optimizer):
 
     def reduce_gradients_async(self):
         """Start the gradient all-reduce of the whole buffer (call right after backward); step() waits for it."""
-        if self.world_size > 1 and self._pending is None:
+        if self._collectives and self._pending is None:
             self._install_grad_views()
             self.bucket_log = []
             self.reduce_range_async(0, self._total)
@@ -102,7 +106,7 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             raise NotImplementedError("closures are not supported")
         self._install_grad_views()
-        if self.world_size > 1:
+        if self._collectives:
             self.reduce_gradients_async()
             self.wait_gradients()
         self.step_local()

@@ -72,3 +72,21 @@ def test_bench_launches_its_own_ranks():
     assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out
     assert out["value"] > 0 and out["scaling"] == "weak"
 
+
+
+def test_bench_step_against_real_rccl_with_one_rank():
+    """The N-rank call sequence (4 gradient buckets all-reduced between graph replays, D exchange, waits, Adam) against
+    the real RCCL backend: a one-rank 'nccl' group with the collectives forced on (P2PHD_REHEARSE_RCCL) -- what a
+    one-GPU box can exercise of the path the driver's multi-GPU bench takes."""
+    import json
+    env = dict(os.environ, P2PHD_REHEARSE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "P2PHD_DIST_BACKEND", "P2PHD_FORCE_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
+           "--no-mdct"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["dist"]["backend"] == "nccl" and out["dist"]["rehearsal_one_rank"] is True
+    assert len(out["dist"]["g_gradient_buckets"]) == 4 and min(out["dist"]["g_gradient_buckets"]) > 0
+    assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out and out["value"] > 0

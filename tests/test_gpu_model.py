@@ -399,7 +399,7 @@ def test_staged_backward_equals_single_backward(golden_model):
     # the staged capture: A0 .. A3 | B | C
     for _ in range(4):
         four.train_step_graphed(lr, hr)
-    gA, ranges, _, _ = four._graph_state['graphs']
+    gA, ranges, _, _, _ = four._graph_state['graphs']
     assert len(gA) == 4 and ranges == bk
     _reset(one, g); _reset(four, g)
     one.train_step(lr, hr)
