@@ -86,7 +86,7 @@ __device__ unsigned long long g_probe[kProbeSlots * 8];   // one record per work
 #endif
 
 template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
-__global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
+__global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
                                                     const float* __restrict__ bias,
                                                     const typename OutOf<T>::type* __restrict__ addend,
                                                     typename OutOf<T>::type* __restrict__ out, float* __restrict__ stats) {
@@ -94,14 +94,15 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   constexpr int EPPO = Elem<TO>::EPP;
   constexpr int EPP = Elem<T>::EPP;
   constexpr int BK = 8 * EPP;
-  constexpr int NT = BM * 2;                                  // threads: one wave per 64 x 64 (or narrower) sub-tile
   constexpr int WGM = BM / (MR * 32), WGN = BN / (NR * 32);
-  static_assert(WGM * WGN * 64 == NT, "tile config");
+  constexpr int NT = WGM * WGN * 64;                          // threads: one wave per (MR*32) x (NR*32) sub-tile
+  static_assert(NT == BM * 2 || NT == BM, "tile config");
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int RS = NT / 8;                                  // row distance between a thread's pieces
   constexpr int NB = BN * 8 / NT;                             // B pieces per thread per step
-  static_assert(NB >= 1 && BM * 8 / NT == 4, "piece distribution");
-  constexpr int NLOADS = 4 + NB;                              // direct-to-LDS loads per thread per stage
+  constexpr int NA = BM * 8 / NT;                             // A pieces per thread per step (4, or 8 with one wave per SIMD)
+  static_assert(NB >= 1 && (NA == 4 || NA == 8), "piece distribution");
+  constexpr int NLOADS = NA + NB;                             // direct-to-LDS loads per thread per stage
 
   // descriptor fields used in loops live in registers (a by-value struct that is captured by reference ends
   // up in scratch memory)
@@ -171,7 +172,9 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
   const int CpB = Cp * SZ;
   int a_t = (kchunk * EPP) / Cp, a_cB = ((kchunk * EPP) % Cp) * SZ;
   int cur_t = -1;
-  unsigned aoffb[4] = {kOOB, kOOB, kOOB, kOOB}, va[4];
+  unsigned aoffb[NA], va[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) aoffb[i] = kOOB;
   unsigned boffb[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) boffb[i] = (unsigned)(((size_t)(n0 + rbase + RS * i) * KK + kchunk * EPP) * SZ);
@@ -186,32 +189,32 @@ __global__ __launch_bounds__(BM * 2) void gconv_kernel(const GDesc d, const T* _
       cur_t = a_t;
       if (a_t < T_taps) {
         // asm: a C++ LDS read here would make hipcc drain the LDS-DMA queue (see compute)
-        int ro[4];
+        int ro[NA];
         const unsigned ta = tab_base + (unsigned)(a_t * BM + rbase) * 4u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(ro[i]) : "v"(ta + (unsigned)(RS * i * 4)));
+        for (int i = 0; i < NA; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(ro[i]) : "v"(ta + (unsigned)(RS * i * 4)));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aoffb[i] = ro[i] >= 0 ? (unsigned)ro[i] * (unsigned)CpB : kOOB;
+        for (int i = 0; i < NA; ++i) aoffb[i] = ro[i] >= 0 ? (unsigned)ro[i] * (unsigned)CpB : kOOB;
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) aoffb[i] = kOOB;
+        for (int i = 0; i < NA; ++i) aoffb[i] = kOOB;
       }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) va[i] = aoffb[i] == kOOB ? kOOB : aoffb[i] + (unsigned)a_cB;
+    for (int i = 0; i < NA; ++i) va[i] = aoffb[i] == kOOB ? kOOB : aoffb[i] + (unsigned)a_cB;
     a_cB += kRowBytes;
     while (a_cB >= CpB) { a_cB -= CpB; ++a_t; }
   };
-  // piece j of a tile: 0..3 = A rows rbase + RS j, 4.. = B rows; tile = K-slab index (scalar offset of B)
+  // piece j of a tile: 0..NA-1 = A rows rbase + RS j, NA.. = B rows; tile = K-slab index (scalar offset of B)
   auto issue_piece = [&](int slot, int tile, int j) {
     char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
-    if (j < 4) {
+    if (j < NA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(A + RS * j * kRowBytes), 16, (int)va[j], 0, 0, 0);
     } else {
       char* B = A + BM * kRowBytes;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(B + RS * (j - 4) * kRowBytes), 16, (int)boffb[j - 4],
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(B + RS * (j - NA) * kRowBytes), 16, (int)boffb[j - NA],
                                                tile * kRowBytes, 0, 0);
     }
   };
@@ -1329,7 +1332,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (probe) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
   typedef typename OutOf<T>::type TO;
-  hipLaunchKernelGGL(kern, grid, dim3(BM * 2), lds, st, d, (const T*)in, (const T*)wp, bias, (const TO*)addend, (TO*)out, stats);
+  hipLaunchKernelGGL(kern, grid, dim3((BM / (MR * 32)) * (BN / (NR * 32)) * 64), lds, st, d, (const T*)in, (const T*)wp, bias, (const TO*)addend, (TO*)out, stats);
   if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
 }

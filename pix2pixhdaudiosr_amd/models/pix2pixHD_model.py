@@ -356,24 +356,26 @@ class Pix2PixHDModel(BaseModel):
         total = optG._total
         if not cuts:
             def whole():
-                with _ops.backward_without_weight_grads(optD._params):
+                with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream():
                     loss_G.backward(inputs=list(optG._params), retain_graph=True)
             return [(whole, (0, total))]
         state = {}
         stages = []
 
         def head():
-            with _ops.backward_without_weight_grads(optD._params):
+            with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream():
                 (state['g'],) = torch.autograd.grad(loss_G, [cuts[-1]], retain_graph=True)
         stages.append((head, (offs[-1], total)))
         for i in range(len(cuts) - 2, -1, -1):
             def mid(i=i):
-                (state['g'],) = torch.autograd.grad(cuts[i + 1], [cuts[i]], grad_outputs=state['g'], retain_graph=True)
+                with _ops.wgrad_side_stream():
+                    (state['g'],) = torch.autograd.grad(cuts[i + 1], [cuts[i]], grad_outputs=state['g'], retain_graph=True)
             stages.append((mid, (offs[i], offs[i + 1])))
         first_params = [p for p, o in zip(optG._params, optG._offs) if o < offs[0]]
 
         def tail():
-            cuts[0].backward(gradient=state['g'], inputs=first_params, retain_graph=True)
+            with _ops.wgrad_side_stream():
+                cuts[0].backward(gradient=state['g'], inputs=first_params, retain_graph=True)
             state.clear()
         stages.append((tail, (0, offs[0])))
         return stages
@@ -392,7 +394,7 @@ class Pix2PixHDModel(BaseModel):
         """Backward of the discriminator loss through the graph phase A kept."""
         loss_D, self._loss_D = self._loss_D, None
         firsts = [self.netD._scale_steps(d)[0][0].spec for d in range(self.opt.num_D)]
-        with _ops.backward_without_input_grads(firsts):            # no gradient towards the generator in this pass
+        with _ops.backward_without_input_grads(firsts), _ops.wgrad_side_stream():   # no gradient towards the generator in this pass
             loss_D.backward(inputs=list(self.optimizer_D._params))
 
     def train_step(self, lr_audio, hr_audio, noise=None):

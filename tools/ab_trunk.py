@@ -14,16 +14,21 @@ def run(batch=32, cin=768, cout=768, H=32, W=16, k=3, pad=1, pad_mode=1, rounds=
     Ho, Wo = spec.out_size(d)
     wp = spec.packed(w, 0, d)
     y = torch.empty(batch, Ho, Wo, _ops.cpitch(cout), device="cuda", dtype=torch.bfloat16)
+    yref = None
     stats = torch.zeros(batch, _ops.cpitch(cout), 2, device="cuda")
     L = _ops.lib()
     ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 16), dtype=torch.uint8, device="cuda")
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
     flops = 2.0 * batch * Ho * Wo * cin * cout * k * k
-    res = {0: [], 128: [], 256: [], 512: []}
+    variants = tuple(int(v) for v in os.environ.get('VARIANTS', '0,128,256,512').split(','))
+    res = {v: [] for v in variants}
     for r in range(rounds):
-        for bm in (0, 128, 256, 512):
+        for bm in variants:
             _lib.check(L.p2phd_set_option(b"gconv_bm", bm))
             call(); torch.cuda.synchronize()
+            if r == 0:                                            # every variant must produce the same tensor
+                if yref is None: yref = y.clone()
+                else: assert torch.equal(yref, y) or float((yref.float() - y.float()).abs().max()) < 1e-2, (bm, float((yref.float() - y.float()).abs().max()))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
