@@ -241,6 +241,13 @@ int64_t p2phd_spectro_partials_floats(int64_t B, int64_t F, int64_t M);
 int p2phd_spectro_encode(const float* spec, int64_t B, int64_t F, int64_t M, float alpha, float min_value,
                          int mask_rows, const float* noise, float* log_spectro, float* pha, float* norm8,
                          float* partials, void* stream);
+/* The general form (pix2pixHD_model.py:149-162,196-226).  channels = 2: explicit encoding as above; channels = 1:
+ * log_spectro [B,1,M,F] = amplitude_to_DB(|spec| + min_value) min-max scaled, the sign in pha.  mask_mode 0 / 1 / 2 =
+ * the reference's 'mode0' (noise / (max - min)), 'mode1' (min-max scaled noise times noise_sign, a +-1 tensor shaped
+ * like noise) and 'mode2' (min-max scaled noise); noise == NULL = zeros (mask_mode None).  noise: [B,channels,mask_rows,F]. */
+int p2phd_spectro_encode_ex(const float* spec, int64_t B, int64_t F, int64_t M, int channels, float alpha, float min_value,
+                            int mask_rows, int mask_mode, const float* noise, const float* noise_sign, float* log_spectro,
+                            float* pha, float* norm8, float* partials, void* stream);
 int p2phd_spectro_decode(const float* log_spectro, const float* norm_min_max, int64_t B, int64_t F, int64_t M,
                          float alpha, float min_value, float* spec, void* stream);
 

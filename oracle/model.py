@@ -6,7 +6,7 @@ Restates (paths relative to the reference checkout):
 
   amplitude_to_DB / DB_to_amplitude   torchaudio.functional (absent from the image; formulae
                                       pinned by test/metrics_test.ipynb cell 11)
-  to_spectro       models/pix2pixHD_model.py:142-227  (explicit encoding, mask mode2/None)
+  to_spectro       models/pix2pixHD_model.py:142-227  (explicit and single-channel encoding, every mask / phase mode)
   denormalize      models/pix2pixHD_model.py:229-232
   to_audio         models/pix2pixHD_model.py:234-249
   forward (losses) models/pix2pixHD_model.py:331-435
@@ -55,30 +55,51 @@ def mdct4_torch(audio, opt, window):
     return torch.from_numpy(spec)
 
 
-def to_spectro(audio, opt, window, mask=False, noise=None):
+def to_spectro(audio, opt, window, mask=False, noise=None, phase_noise=None, noise_sign=None):
     """pix2pixHD_model.py:142-227.  The MDCT output (fp64 in the reference) is cast to fp32
-    right after the transform -- the documented choice of this build."""
+    right after the transform -- the documented choice of this build.  The tensors the reference draws
+    inside (`noise`: randn of :202, `noise_sign`: 2 * randint - 1 of :215, `phase_noise`: rand / randn of :180-188)
+    are arguments here."""
     up_ratio = opt.hr_sampling_rate / opt.lr_sampling_rate
     spectro = mdct4_torch(audio, opt, window).to(torch.float32)
     spectro = spectro.unsqueeze(1).permute(0, 1, 3, 2)                     # :147
-    neg = 0.5 * (torch.abs(spectro) - spectro)                              # :150
-    pos = spectro + neg
-    a = opt.alpha
-    log_spectro = torch.cat((amplitude_to_DB(a * pos + (1 - a) * neg, 20, opt.min_value, 1),
-                             amplitude_to_DB((1 - a) * pos + a * neg, 20, opt.min_value, 1)), dim=1)
+    explicit = getattr(opt, "explicit_encoding", True)
+    if explicit:
+        neg = 0.5 * (torch.abs(spectro) - spectro)                          # :150
+        pos = spectro + neg
+        a = opt.alpha
+        log_spectro = torch.cat((amplitude_to_DB(a * pos + (1 - a) * neg, 20, opt.min_value, 1),
+                                 amplitude_to_DB((1 - a) * pos + a * neg, 20, opt.min_value, 1)), dim=1)
+    else:
+        log_spectro = amplitude_to_DB(torch.abs(spectro) + opt.min_value, 20, opt.min_value, 1)   # :160-162
     pha = torch.sign(spectro)                                               # :163
     mean = log_spectro.mean()
     std = log_spectro.var().sqrt()
     amax = log_spectro.max()
     amin = log_spectro.min()
+    if not explicit:                                                        # :178-191
+        pem = getattr(opt, "phase_encoding_mode", None)
+        if pem == "uni_dist":
+            pha = pha * phase_noise
+        elif pem == "norm_dist":
+            pha = pha * ((phase_noise - phase_noise.min()) / (phase_noise.max() - phase_noise.min()))
+        elif pem == "norm_dist2":
+            pha = pha * phase_noise.abs()
+        elif pem == "scale":
+            pha = pha * 0.5
     log_spectro = (log_spectro - amin) / (amax - amin)                      # :193
     if mask:
         size = log_spectro.size()
         mask_size = int(size[2] * (1 - 1 / up_ratio))                       # :199
-        if opt.mask_mode == "mode2":
+        if opt.mask_mode in ("mode0", "mode1", "mode2"):
             assert noise is not None and tuple(noise.shape) == (size[0], size[1], mask_size, size[3])
             nmin, nmax = noise.min(), noise.max()
-            fill = (noise - nmin) / (nmax - nmin)                           # :219
+            if opt.mask_mode == "mode0":
+                fill = noise / (nmax - nmin)                                # :209
+            else:
+                fill = (noise - nmin) / (nmax - nmin)                       # :213 / :219
+                if opt.mask_mode == "mode1":
+                    fill = fill * noise_sign                                # :215-216
         elif opt.mask_mode is None:
             fill = torch.zeros(size[0], size[1], mask_size, size[3])
         else:
@@ -92,11 +113,19 @@ def denormalize(log_spectro, norm_param, opt):
     return DB_to_amplitude(s, 10, 0.5) - opt.min_value                      # :232
 
 
-def to_audio(log_spectro, norm_param, opt, window):
+def to_audio(log_spectro, norm_param, opt, window, pha=None, pseudo_pha=None):
     """pix2pixHD_model.py:234-249 with IMDCT4 as the inverse transform."""
     up_ratio = opt.hr_sampling_rate / opt.lr_sampling_rate
     s = denormalize(log_spectro, norm_param, opt)
-    s = (s[..., 0, :, :] - s[..., 1, :, :]) / (2 * opt.alpha - 1)           # :237
+    if getattr(opt, "explicit_encoding", True):
+        s = (s[..., 0, :, :] - s[..., 1, :, :]) / (2 * opt.alpha - 1)       # :237
+    else:
+        if up_ratio > 1:                                                    # :239-243 (pseudo_pha: the randint of :240)
+            size = pha.size(-2)
+            keep = int(size * (1 / up_ratio))
+            pha = torch.cat((pha[..., :keep, :], pseudo_pha[..., keep:, :].to(pha.dtype)), dim=-2)
+            s = s * pha
+        s = s.squeeze(1)                                                    # :248
     audio = M.imdct4_forward(s.permute(0, 2, 1).contiguous().numpy(), opt.n_fft, opt.hop_length,
                              opt.win_length, window, opt.center)
     return math.sqrt(up_ratio - 1) * torch.from_numpy(audio)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_spectro_encode_ex": (_i32, [_vp, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_decode": (_i32, [_vp, _vp, _i64, _i64, _i64, _f32, _f32, _vp, _vp]),
     "p2phd_spectro_decode_signed": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _vp, _vp]),
     "p2phd_stft_tables_floats": (_sz, [_i32]),

@@ -1,5 +1,6 @@
 // Spectrogram codec around the MDCT: Pix2PixHDModel.to_spectro / denormalize / to_audio
-// (models/pix2pixHD_model.py:142-249) for the explicit-encoding configuration the published runs use.
+// (models/pix2pixHD_model.py:142-249): the explicit two-channel encoding of the published runs and the single-channel
+// magnitude encoding, every mask_mode.
 //
 // encode: spec[B,F,M] (frames x bins, MDCT4 output) -> log_spectro[B,2,M,F] in [0,1], pha[B,1,M,F]
 //   pass 1  transposes through a 32x32 LDS tile (reads coalesced along bins, writes coalesced along frames),
@@ -31,7 +32,7 @@ __device__ __forceinline__ void block_reduce4(float mn, float mx, float s1, floa
 
 __global__ __launch_bounds__(256) void encode_pass1_kernel(const float* __restrict__ spec, float* __restrict__ db,
                                                            float* __restrict__ pha, float* __restrict__ partials, int F,
-                                                           int M, float alpha, float min_value) {
+                                                           int M, float alpha, float min_value, int channels) {
   __shared__ float tile[32][33];
   const int b = blockIdx.z, m0 = blockIdx.x * 32, f0 = blockIdx.y * 32;
   const int tx = threadIdx.x, ty = threadIdx.y;
@@ -45,16 +46,23 @@ __global__ __launch_bounds__(256) void encode_pass1_kernel(const float* __restri
     const int m = m0 + ty + 8 * i, f = f0 + tx;
     if (m < M && f < F) {
       const float s = tile[tx][ty + 8 * i];
-      const float neg = 0.5f * (fabsf(s) - s);
-      const float pos = s + neg;
-      const float d0 = 20.f * log10f(fmaxf(alpha * pos + (1.f - alpha) * neg, min_value)) - 20.f;
-      const float d1 = 20.f * log10f(fmaxf((1.f - alpha) * pos + alpha * neg, min_value)) - 20.f;
-      const size_t o = ((size_t)b * 2 * M + m) * F + f;
-      db[o] = d0;
-      db[o + (size_t)M * F] = d1;
       pha[((size_t)b * M + m) * F + f] = s > 0.f ? 1.f : (s < 0.f ? -1.f : 0.f);
-      mn = fminf(mn, fminf(d0, d1)); mx = fmaxf(mx, fmaxf(d0, d1));
-      s1 += d0 + d1; s2 += d0 * d0 + d1 * d1;
+      if (channels == 2) {                                       // explicit encoding (:149-158)
+        const float neg = 0.5f * (fabsf(s) - s);
+        const float pos = s + neg;
+        const float d0 = 20.f * log10f(fmaxf(alpha * pos + (1.f - alpha) * neg, min_value)) - 20.f;
+        const float d1 = 20.f * log10f(fmaxf((1.f - alpha) * pos + alpha * neg, min_value)) - 20.f;
+        const size_t o = ((size_t)b * 2 * M + m) * F + f;
+        db[o] = d0;
+        db[o + (size_t)M * F] = d1;
+        mn = fminf(mn, fminf(d0, d1)); mx = fmaxf(mx, fmaxf(d0, d1));
+        s1 += d0 + d1; s2 += d0 * d0 + d1 * d1;
+      } else {                                                   // magnitude only (:159-162); the sign travels in pha
+        const float d0 = 20.f * log10f(fmaxf(fabsf(s) + min_value, min_value)) - 20.f;
+        db[((size_t)b * M + m) * F + f] = d0;
+        mn = fminf(mn, d0); mx = fmaxf(mx, d0);
+        s1 += d0; s2 += d0 * d0;
+      }
     }
   }
   const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -90,12 +98,15 @@ __global__ __launch_bounds__(256) void finalize4_kernel(const float* __restrict_
   }
 }
 
+// mask_mode (:207-221): 0 = noise / (max - min) (single peak at 0), 1 = min-max scaled noise times a random sign,
+// 2 = min-max scaled noise; no noise pointer = zeros (mask_mode None)
 __global__ __launch_bounds__(256) void encode_pass2_kernel(float* __restrict__ db, const float* __restrict__ norm4,
                                                            const float* __restrict__ noise, const float* __restrict__ nnorm4,
-                                                           int M, int F, int mask_rows, long total) {
+                                                           int M, int F, int mask_rows, long total, int mask_mode,
+                                                           const float* __restrict__ noise_sign) {
   const float mn = norm4[0], scale = 1.f / (norm4[1] - norm4[0]);
   float nmn = 0.f, nscale = 0.f;
-  if (noise != nullptr) { nmn = nnorm4[0]; nscale = 1.f / (nnorm4[1] - nnorm4[0]); }
+  if (noise != nullptr) { nmn = mask_mode == 0 ? 0.f : nnorm4[0]; nscale = 1.f / (nnorm4[1] - nnorm4[0]); }
   const int keep = M - mask_rows;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int f = (int)(e % F);
@@ -104,7 +115,11 @@ __global__ __launch_bounds__(256) void encode_pass2_kernel(float* __restrict__ d
     const long bc = r / M;                                     // b*2 + channel
     float v;
     if (m < keep) v = (db[e] - mn) * scale;
-    else v = noise != nullptr ? (noise[(bc * mask_rows + (m - keep)) * F + f] - nmn) * nscale : 0.f;
+    else if (noise != nullptr) {
+      const long q = (bc * mask_rows + (m - keep)) * F + f;
+      v = (noise[q] - nmn) * nscale;
+      if (mask_mode == 1) v *= noise_sign[q];
+    } else v = 0.f;
     db[e] = v;
   }
 }
@@ -173,31 +188,42 @@ extern "C" int64_t p2phd_spectro_partials_floats(int64_t B, int64_t F, int64_t M
   return 4 * B * ((F + 31) / 32) * ((M + 31) / 32) + 4 * 1024;   // encode blocks + noise-statistics blocks
 }
 
-extern "C" int p2phd_spectro_encode(const float* spec, int64_t B, int64_t F, int64_t M, float alpha, float min_value,
-                                    int mask_rows, const float* noise, float* log_spectro, float* pha, float* norm4,
-                                    float* partials, void* stream) {
+extern "C" int p2phd_spectro_encode_ex(const float* spec, int64_t B, int64_t F, int64_t M, int channels, float alpha,
+                                       float min_value, int mask_rows, int mask_mode, const float* noise,
+                                       const float* noise_sign, float* log_spectro, float* pha, float* norm4, float* partials,
+                                       void* stream) {
   P2PHD_REQUIRE(B >= 0 && F >= 1 && M >= 1 && mask_rows >= 0 && mask_rows <= M, "spectro_encode: bad geometry");
+  P2PHD_REQUIRE(channels == 1 || channels == 2, "spectro_encode: channels must be 2 (explicit encoding) or 1");
+  P2PHD_REQUIRE(mask_mode >= 0 && mask_mode <= 2, "spectro_encode: mask_mode must be 0, 1 or 2");
   if (B == 0) return P2PHD_OK;
   P2PHD_REQUIRE(spec && log_spectro && pha && norm4 && partials, "spectro_encode: null pointer");
+  P2PHD_REQUIRE(!(mask_mode == 1 && noise != nullptr && mask_rows > 0 && noise_sign == nullptr), "spectro_encode: mask mode1 needs the sign tensor");
   P2PHD_REQUIRE(B < 65536 && (F + 31) / 32 < 65536, "spectro_encode: grid too large");
   hipStream_t st = (hipStream_t)stream;
   dim3 grid((unsigned)((M + 31) / 32), (unsigned)((F + 31) / 32), (unsigned)B);
   const int nblk = (int)(grid.x * grid.y * grid.z);
-  hipLaunchKernelGGL(encode_pass1_kernel, grid, dim3(32, 8), 0, st, spec, log_spectro, pha, partials, (int)F, (int)M, alpha, min_value);
-  hipLaunchKernelGGL(finalize4_kernel, dim3(1), dim3(256), 0, st, partials, nblk, (double)(2 * B * F * M), norm4);
+  hipLaunchKernelGGL(encode_pass1_kernel, grid, dim3(32, 8), 0, st, spec, log_spectro, pha, partials, (int)F, (int)M, alpha, min_value, channels);
+  hipLaunchKernelGGL(finalize4_kernel, dim3(1), dim3(256), 0, st, partials, nblk, (double)(channels * B * F * M), norm4);
   float* npart = partials + 4 * (size_t)nblk;
   float* nnorm = norm4 + 4;
   if (noise != nullptr && mask_rows > 0) {
-    const long n = 2 * B * mask_rows * F;
+    const long n = channels * B * mask_rows * F;
     const int nb = (int)std::min<long>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(stats4_kernel, dim3(nb), dim3(256), 0, st, noise, n, npart);
     hipLaunchKernelGGL(finalize4_kernel, dim3(1), dim3(256), 0, st, npart, nb, (double)n, nnorm);
   }
-  const long total = 2 * B * M * F;
+  const long total = channels * B * M * F;
   const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
   hipLaunchKernelGGL(encode_pass2_kernel, dim3(blocks), dim3(256), 0, st, log_spectro, norm4, mask_rows > 0 ? noise : nullptr,
-                     nnorm, (int)M, (int)F, mask_rows, total);
+                     nnorm, (int)M, (int)F, mask_rows, total, mask_mode, noise_sign);
   return p2phd::check_launch("spectro_encode");
+}
+
+extern "C" int p2phd_spectro_encode(const float* spec, int64_t B, int64_t F, int64_t M, float alpha, float min_value,
+                                    int mask_rows, const float* noise, float* log_spectro, float* pha, float* norm4,
+                                    float* partials, void* stream) {
+  return p2phd_spectro_encode_ex(spec, B, F, M, 2, alpha, min_value, mask_rows, 2, noise, nullptr, log_spectro, pha, norm4,
+                                 partials, stream);
 }
 
 extern "C" int p2phd_spectro_decode(const float* log_spectro, const float* norm_min_max, int64_t B, int64_t F, int64_t M,

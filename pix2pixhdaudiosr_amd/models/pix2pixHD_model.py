@@ -11,8 +11,8 @@ Deliberate differences:
     reference hard-codes MDCT2 (pix2pixHD_model.py:37-40) and invites the swap in README.md:133; ``opt.mdct_type =
     'mdct2'`` selects the reference's own MDCT2/IMDCT2 (n_fft bins) and enables to_frames / --use_match_loss;
   * MDCT output is fp32 (the reference's complex128 twiddles make it fp64, which its own fp32 convs reject);
-  * only the configuration the published runs use is on the path: explicit_encoding, mask_mode in
-    {None, 'mode2'}, LSGAN, no VGG / hifigan / time-domain discriminator / feature encoder;
+  * every to_spectro configuration (explicit two-channel or single-channel encoding, all mask / phase modes);
+    LSGAN, no VGG / hifigan / time-domain discriminator / feature encoder;
   * the D weight gradients of the G-loss pass are not computed (train.py:176 zeroes them unread);
   * the per-step device->host copies of pix2pixHD_model.py:418-428 are deferred to get_current_visuals();
   * ``--fp16`` selects bf16 MFMA compute with fp32 master weights instead of fp16 autocast + GradScaler;
@@ -52,10 +52,12 @@ class Pix2PixHDModel(BaseModel):
 
     def _check_supported(self, opt):
         unsupported = []
-        if not _opt(opt, 'explicit_encoding', False):
-            unsupported.append("explicit_encoding must be set (the published configuration)")
-        if _opt(opt, 'mask_mode', None) not in (None, 'mode2'):
-            unsupported.append("mask_mode must be None or 'mode2'")
+        if _opt(opt, 'mask_mode', None) not in (None, 'mode0', 'mode1', 'mode2'):
+            unsupported.append("mask_mode must be None, 'mode0', 'mode1' or 'mode2'")
+        if _opt(opt, 'phase_encoding_mode', None) not in (None, 'uni_dist', 'norm_dist', 'norm_dist2', 'scale'):
+            unsupported.append("phase_encoding_mode must be None, 'uni_dist', 'norm_dist', 'norm_dist2' or 'scale'")
+        if not _opt(opt, 'explicit_encoding', False) and _opt(opt, 'use_match_loss', False):
+            unsupported.append("--use_match_loss needs explicit_encoding (to_frames returns None without it, pix2pixHD_model.py:255-256)")
         for flag in ('use_hifigan_D', 'use_time_D', 'instance_feat', 'label_feat'):
             if _opt(opt, flag, False):
                 unsupported.append("--%s is outside the HIP hot path" % flag)
@@ -154,31 +156,57 @@ class Pix2PixHDModel(BaseModel):
     # ------------------------------------------------------------------------------------------
     # spectrogram codec (HIP: csrc/spectro.hip)
     # ------------------------------------------------------------------------------------------
-    def to_spectro(self, audio, mask=False, noise=None):
-        """audio [B,T] -> (log_spectro [B,2,bins,frames] in [0,1], pha [B,1,bins,frames], norm dict).
-        ``noise`` ([B,2,mask_rows,frames]) replaces the torch.randn draw of pix2pixHD_model.py:202 when given."""
+    def to_spectro(self, audio, mask=False, noise=None, phase_noise=None, noise_sign=None):
+        """audio [B,T] -> (log_spectro [B,C,bins,frames] in [0,1], pha [B,1,bins,frames], norm dict); C = 2 with
+        explicit_encoding, else 1 (pix2pixHD_model.py:142-227).  The random tensors the reference draws inside can be
+        handed in (parity tests): ``noise`` [B,C,mask_rows,frames] (torch.randn of :202), ``noise_sign`` (+-1, the randint of
+        :215 for mask_mode 'mode1'), ``phase_noise`` [B,1,bins,frames] (the rand / randn of :180-188)."""
         spec = self._mdct(audio.to(self.device))                            # [B, frames, bins] f32
         B, Fr, M = spec.shape
         L = _lib.lib()
-        log_spectro = torch.empty((B, 2, M, Fr), dtype=torch.float32, device=spec.device)
+        explicit = bool(_opt(self.opt, 'explicit_encoding', False))
+        C = 2 if explicit else 1
+        pem = None if explicit else _opt(self.opt, 'phase_encoding_mode', None)
+        if pem in ('uni_dist', 'norm_dist', 'norm_dist2') and phase_noise is None:      # drawn first, as the reference does
+            phase_noise = (torch.rand if pem == 'uni_dist' else torch.randn)((B, 1, M, Fr), device=spec.device)
+        log_spectro = torch.empty((B, C, M, Fr), dtype=torch.float32, device=spec.device)
         pha = torch.empty((B, 1, M, Fr), dtype=torch.float32, device=spec.device)
         norm8 = torch.zeros(8, dtype=torch.float32, device=spec.device)
         partials = torch.empty(L.p2phd_spectro_partials_floats(B, Fr, M), dtype=torch.float32, device=spec.device)
         mask_rows = 0
+        mode = _opt(self.opt, 'mask_mode', None)
         if mask:
             mask_rows = int(M * (1 - 1 / self.up_ratio))                    # pix2pixHD_model.py:199
-            if self.opt.mask_mode == 'mode2':
+            if mode in ('mode0', 'mode1', 'mode2'):
                 if noise is None:
-                    noise = torch.randn(B, 2, mask_rows, Fr, device=spec.device)
+                    noise = torch.randn(B, C, mask_rows, Fr, device=spec.device)
                 noise = noise.to(spec.device).float().contiguous()
-                assert tuple(noise.shape) == (B, 2, mask_rows, Fr)
+                assert tuple(noise.shape) == (B, C, mask_rows, Fr)
+                if mode == 'mode1':
+                    if noise_sign is None:
+                        noise_sign = 2 * torch.randint(low=0, high=2, size=noise.size(), device=spec.device) - 1
+                    noise_sign = noise_sign.to(spec.device).float().contiguous()
+                    assert noise_sign.shape == noise.shape
+                else:
+                    noise_sign = None
             else:
-                noise = None
+                noise = noise_sign = None
         else:
-            noise = None
-        _lib.check(L.p2phd_spectro_encode(_lib.ptr(spec), B, Fr, M, float(self.opt.alpha), float(self.opt.min_value),
-                                          mask_rows, _lib.ptr(noise), _lib.ptr(log_spectro), _lib.ptr(pha), _lib.ptr(norm8),
-                                          _lib.ptr(partials), _lib.stream_ptr()), "spectro_encode")
+            noise = noise_sign = None
+        _lib.check(L.p2phd_spectro_encode_ex(_lib.ptr(spec), B, Fr, M, C, float(self.opt.alpha), float(self.opt.min_value),
+                                             mask_rows, {'mode0': 0, 'mode1': 1}.get(mode, 2), _lib.ptr(noise),
+                                             _lib.ptr(noise_sign), _lib.ptr(log_spectro), _lib.ptr(pha), _lib.ptr(norm8),
+                                             _lib.ptr(partials), _lib.stream_ptr()), "spectro_encode")
+        if pem is not None:                                                 # :178-191 (single-channel encoding only)
+            if pem == 'scale':
+                pha = pha * 0.5
+            else:
+                pn = phase_noise.to(spec.device).float()
+                if pem == 'norm_dist':
+                    pn = (pn - pn.min()) / (pn.max() - pn.min())
+                elif pem == 'norm_dist2':
+                    pn = pn.abs()
+                pha = pha * pn
         norm = {'min': norm8[0], 'max': norm8[1], 'mean': norm8[2], 'std': norm8[3], 'frames': None, '_minmax': norm8[:2]}
         return log_spectro, pha, norm
 
@@ -194,10 +222,26 @@ class Pix2PixHDModel(BaseModel):
         s = torch.abs(log_spectro) * (mm[1] - mm[0]) + mm[0]
         return 10.0 * torch.pow(10.0, s * 0.05) - self.opt.min_value        # DB_to_amplitude(s, 10, 0.5) - min_value
 
-    def to_audio(self, log_spectro, norm_param, pha=None):
+    def to_audio(self, log_spectro, norm_param, pha=None, pseudo_pha=None):
         x = log_spectro.to(self.device).float().contiguous()
         B, _, M, Fr = x.shape
         spec = torch.empty((B, Fr, M), dtype=torch.float32, device=x.device)
+        if not _opt(self.opt, 'explicit_encoding', False):
+            # single-channel encoding (pix2pixHD_model.py:238-249): amplitude times pha on the bins the low-rate input
+            # carries and times a random sign above (``pseudo_pha`` replaces the randint of :240); with up_ratio <= 1 the
+            # reference never applies the sign at all
+            if self.up_ratio > 1:
+                keep = int(M * (1 / self.up_ratio))
+                if pseudo_pha is None:
+                    pseudo_pha = 2 * torch.randint(low=0, high=2, size=pha.size(), device=x.device) - 1
+                sign = torch.cat((pha.to(x.device).float()[..., :keep, :], pseudo_pha.to(x.device).float()[..., keep:, :]), dim=-2)
+            else:
+                sign = torch.ones((B, 1, M, Fr), dtype=torch.float32, device=x.device)
+            sign = sign.reshape(B, M, Fr).contiguous()
+            _lib.check(_lib.lib().p2phd_spectro_decode_signed(_lib.ptr(x), _lib.ptr(sign), _lib.ptr(self._minmax(norm_param)), B, Fr,
+                                                              M, 1, M, float(self.opt.min_value), 1.0, _lib.ptr(spec),
+                                                              _lib.stream_ptr()), "spectro_decode")
+            return np.sqrt(self.up_ratio - 1) * self._imdct(spec)
         _lib.check(_lib.lib().p2phd_spectro_decode(_lib.ptr(x), _lib.ptr(self._minmax(norm_param)), B, Fr, M,
                                                    float(self.opt.alpha), float(self.opt.min_value), _lib.ptr(spec),
                                                    _lib.stream_ptr()), "spectro_decode")
@@ -206,6 +250,8 @@ class Pix2PixHDModel(BaseModel):
     def to_frames(self, log_spectro, norm_param):
         """Un-windowed time-domain frames of an MDCT2 spectrogram (pix2pixHD_model.py:251-258): differentiable, the
         IDCT runs on the HIP kernel; the small dB decode in front of it is plain tensor arithmetic."""
+        if not _opt(self.opt, 'explicit_encoding', False):
+            return None                                                     # pix2pixHD_model.py:255-256
         if self.mdct_type != 'mdct2':
             raise NotImplementedError("to_frames needs mdct_type='mdct2' (frames are IDCT_2N_native rows)")
         spectro = self.denormalize(log_spectro, norm_param)

@@ -20,7 +20,7 @@ def make_opt(**kw):
              no_lsgan=False, ndf=8, n_layers_D=3, num_D=2, no_ganFeat_loss=False, use_hifigan_D=False, use_time_D=False,
              verbose=False, continue_train=False, load_pretrain="", which_epoch="latest", pool_size=0, lr=0.0002,
              beta1=0.5, no_vgg_loss=True, use_match_loss=False, niter_fix_global=0, explicit_encoding=True, alpha=0.6,
-             min_value=1e-7, mask=True, mask_mode="mode2", lambda_feat=10.0, fp16=False, niter_decay=100,
+             min_value=1e-7, mask=True, mask_mode="mode2", phase_encoding_mode=None, lambda_feat=10.0, fp16=False, niter_decay=100,
              instance_feat=False, label_feat=False)
     o.update(kw)
     return SimpleNamespace(**o)
@@ -51,6 +51,31 @@ def test_to_spectro_and_audio(golden_model):
     aud = m.to_audio(torch.from_numpy(g["hr_spectro"]), {"max": torch.tensor(float(g["hr_max"])), "min": torch.tensor(float(g["hr_min"]))})
     assert tuple(aud.shape) == g["hr_audio_rt"].shape
     assert rel_err(aud.cpu().numpy(), g["hr_audio_rt"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["e_mode0", "e_mode1", "p_none_mode2", "p_uni_nomask", "p_norm_mode0", "p_norm2_mode1", "p_scale_mode2"])
+def test_to_spectro_other_encodings_and_mask_modes(golden_model, name):
+    """mask_mode mode0 / mode1 and the single-channel encoding with every phase_encoding_mode, to_audio included
+    (pix2pixHD_model.py:159-162,178-191,207-221,238-249), against the reference's outputs on the random tensors it drew."""
+    import _spectro_mode_cases as SC
+    g = SC.load()
+    kw = {**dict(explicit_encoding=True, phase_encoding_mode=None, mask_mode="mode2"), **SC.CASES[name]}
+    m = _model(golden_model, **kw)
+    pn, noise, sgn, pseudo = SC.draws(g, name)
+    ls, pha, nrm = m.to_spectro(torch.from_numpy(g["lr"]), mask=True, noise=noise, phase_noise=pn, noise_sign=sgn)
+    assert tuple(ls.shape) == g[f"{name}_spectro"].shape
+    assert rel_err(ls.cpu().numpy(), g[f"{name}_spectro"]) < 1e-4
+    # signs of near-zero bins may flip in fp32; elsewhere pha (sign x phase noise) agrees
+    assert np.mean(np.abs(pha.cpu().numpy() - g[f"{name}_pha"]) > 1e-5) < 2e-3
+    assert abs(float(nrm["max"]) - float(g[f"{name}_max"])) < 1e-3 and abs(float(nrm["min"]) - float(g[f"{name}_min"])) < 2e-2
+    if not kw["explicit_encoding"]:
+        aud = m.to_audio(torch.from_numpy(g[f"{name}_spectro"]), {"max": torch.tensor(float(g[f"{name}_max"])),
+                                                                "min": torch.tensor(float(g[f"{name}_min"]))},
+                         pha=torch.from_numpy(g[f"{name}_pha"]), pseudo_pha=pseudo)
+        assert tuple(aud.shape) == g[f"{name}_audio"].shape and rel_err(aud.cpu().numpy(), g[f"{name}_audio"]) < 1e-4
+    # without handed-in tensors the draws happen on the device: shapes and range only
+    ls2, pha2, _ = m.to_spectro(torch.from_numpy(g["lr"]), mask=True)
+    assert ls2.shape == ls.shape and torch.isfinite(ls2).all() and float(ls2.abs().max()) <= 1.0 + 1e-5
 
 
 def test_forward_losses_grads_and_step(golden_model):
@@ -126,7 +151,9 @@ def test_bf16_step_runs_and_tracks_fp32(golden_model):
 def test_unsupported_configs_raise():
     from pix2pixhdaudiosr_amd.models.models import create_model
     with pytest.raises(NotImplementedError):
-        create_model(make_opt(explicit_encoding=False))
+        create_model(make_opt(use_time_D=True))                    # hifigan discriminator: source absent in the reference
+    with pytest.raises(NotImplementedError):
+        create_model(make_opt(mask_mode="mode7"))
     with pytest.raises(NotImplementedError):
         create_model(make_opt(norm="batch"))
     with pytest.raises(RuntimeError):
@@ -406,3 +433,28 @@ def test_staged_backward_equals_single_backward(golden_model):
     four.train_step_graphed(lr, hr)
     assert _grad_diff(one, four, "optimizer_G") < 2e-2
     assert four.optimizer_G.bucket_log == bk
+
+
+def test_weight_gradients_on_the_side_stream(golden_model, monkeypatch):
+    """P2PHD_WGRAD_STREAM=1: the weight-gradient kernels of the model's backward stages run on a second stream (their
+    operands kept alive until the join).  Same kernels on the same data: the result must agree with the single-stream
+    step to its run-to-run bound, eagerly and replayed from the captured graphs."""
+    g = golden_model
+    lr, hr = _fresh_audio(g)
+    a, b = _model(g, mask=False), _model(g, mask=False)
+    a.train_step(lr, hr)
+    monkeypatch.setenv("P2PHD_WGRAD_STREAM", "1")
+    from pix2pixhdaudiosr_amd import _ops
+    b.train_step(lr, hr)
+    assert _ops._SIDE["stream"] is not None and not _ops._SIDE["keep"] and not _ops._SIDE["on"]
+    torch.cuda.synchronize()
+    assert _grad_diff(a, b, "optimizer_G") < 2e-2 and _grad_diff(a, b, "optimizer_D") < 2e-2
+    for _ in range(4):
+        b.train_step_graphed(lr, hr)
+    assert b._graph_state['graphs'] is not None
+    monkeypatch.setenv("P2PHD_WGRAD_STREAM", "0")
+    _reset(a, g); _reset(b, g)
+    a.train_step(lr, hr)
+    b.train_step_graphed(lr, hr)                                   # the captured side-stream branches replay
+    torch.cuda.synchronize()
+    assert _grad_diff(a, b, "optimizer_G") < 2e-2 and _grad_diff(a, b, "optimizer_D") < 2e-2

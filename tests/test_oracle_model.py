@@ -59,3 +59,29 @@ def test_losses_grads_and_adam(golden_model):
                         {}, opt.lr, opt.beta1)
     for k in pG:
         assert np.max(np.abs(newG[k].numpy() - g[f"G_p1_{k}"])) < 2e-6, k
+
+
+def test_to_spectro_other_encodings_and_mask_modes():
+    """mask_mode mode0 / mode1 and the single-channel encoding with every phase_encoding_mode
+    (pix2pixHD_model.py:159-162,178-191,207-221,238-249) against the reference's own outputs."""
+    import _spectro_mode_cases as SC
+    g = SC.load()
+    w = OM.M.kbdwin(64)
+    lr = torch.from_numpy(g["lr"])
+    for name, kw in SC.CASES.items():
+        opt = _opt()
+        for k, v in {**dict(explicit_encoding=True, phase_encoding_mode=None, mask_mode="mode2"), **kw}.items():
+            setattr(opt, k, v)
+        pn, noise, sgn, pseudo = SC.draws(g, name)
+        ls, pha, nrm = OM.to_spectro(lr, opt, w, mask=True, noise=noise, phase_noise=pn, noise_sign=sgn)
+        assert ls.shape == g[f"{name}_spectro"].shape, name
+        assert rel_err(ls.numpy(), g[f"{name}_spectro"]) < 1e-5, name
+        assert rel_err(pha.numpy(), g[f"{name}_pha"]) < 1e-6, name
+        # the single-channel minimum is the dB value of the smallest |bin| (~1e-7 here, not clamped): its relative rounding
+        # error in the fp32 cast of the transform is amplified by the logarithm
+        assert abs(float(nrm["max"]) - float(g[f"{name}_max"])) < 1e-4 and abs(float(nrm["min"]) - float(g[f"{name}_min"])) < 5e-3
+        if not opt.explicit_encoding:
+            aud = OM.to_audio(torch.from_numpy(g[f"{name}_spectro"]), {"max": torch.tensor(float(g[f"{name}_max"])),
+                                                                     "min": torch.tensor(float(g[f"{name}_min"]))},
+                              opt, w, pha=torch.from_numpy(g[f"{name}_pha"]), pseudo_pha=pseudo)
+            assert aud.shape == g[f"{name}_audio"].shape and rel_err(aud.numpy(), g[f"{name}_audio"]) < 1e-5, name

@@ -369,6 +369,85 @@ def gen_model(out):
     print("model_step.npz", len(d), "arrays; losses", dict(zip(names, d["loss_values"])))
 
 
+def gen_spectro_modes(out):
+    """to_spectro / to_audio of the reference in the configurations besides the published one: mask_mode mode0 / mode1,
+    and the single-channel encoding (explicit_encoding off) with every phase_encoding_mode (pix2pixHD_model.py:142-249).
+    The reference draws its noise with torch.rand / randn / randint inside; the draws are recorded in call order and are
+    inputs of the parity tests."""
+    import contextlib, io
+    from types import SimpleNamespace
+    from models.pix2pixHD_model import Pix2PixHDModel
+    from models.mdct import MDCT4, IMDCT4
+    d = {}
+    base = dict(
+        gpu_ids=[], isTrain=True, checkpoints_dir="/tmp/p2phd_golden", name="g", resize_or_crop="none",
+        instance_feat=False, label_feat=False, load_features=False, label_nc=0, input_nc=2, output_nc=2,
+        hr_sampling_rate=48000, lr_sampling_rate=8000, n_fft=64, hop_length=32, win_length=64, center=True,
+        no_instance=True, feat_num=3, ngf=8, netG="global", n_downsample_global=2, n_blocks_global=2,
+        n_local_enhancers=1, n_blocks_local=1, norm="instance", no_lsgan=False, ndf=8, n_layers_D=3, num_D=2,
+        no_ganFeat_loss=False, use_hifigan_D=False, use_time_D=False, verbose=False, continue_train=False,
+        load_pretrain="", which_epoch="latest", pool_size=0, lr=0.0002, beta1=0.5, no_vgg_loss=True,
+        use_match_loss=False, niter_fix_global=0, explicit_encoding=True, alpha=0.6, min_value=1e-7, mask=True,
+        mask_mode="mode2", phase_encoding_mode=None, lambda_feat=10.0, lambda_mat=10.0, lambda_time=0.4,
+        abs_spectro=True, fp16=False, nef=16, n_downsample_E=4)
+    frames, B = 16, 2
+    T = (frames - 1) * 32
+    g = torch.Generator().manual_seed(99)
+    lr = 0.1 * torch.randn(B, T, generator=g)
+    d["lr"] = _np(lr)
+    cases = [("e_mode0", dict(mask_mode="mode0")), ("e_mode1", dict(mask_mode="mode1")),
+             ("p_none_mode2", dict(explicit_encoding=False)),
+             ("p_uni_nomask", dict(explicit_encoding=False, phase_encoding_mode="uni_dist", mask_mode=None)),
+             ("p_norm_mode0", dict(explicit_encoding=False, phase_encoding_mode="norm_dist", mask_mode="mode0")),
+             ("p_norm2_mode1", dict(explicit_encoding=False, phase_encoding_mode="norm_dist2", mask_mode="mode1")),
+             ("p_scale_mode2", dict(explicit_encoding=False, phase_encoding_mode="scale"))]
+    for name, kw in cases:
+        opt = SimpleNamespace(**dict(base, **kw))
+        torch.manual_seed(1234)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = Pix2PixHDModel()
+            model.initialize(opt)
+        _m4 = MDCT4(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=model.window, device="cpu")
+
+        class _Cast32(torch.nn.Module):
+            def forward(self, a):
+                return _m4(a).float()
+        model._mdct = _Cast32()
+        model._imdct = IMDCT4(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=model.window, device="cpu")
+        draws = []
+        real = {k: getattr(torch, k) for k in ("rand", "randn", "randint")}
+
+        def rec(kind):
+            def f(*a, **k):
+                t = real[kind](*a, **k)
+                draws.append((kind, t.clone()))
+                return t
+            return f
+        torch.manual_seed(555)
+        for k in real:
+            setattr(torch, k, rec(k))
+        try:
+            ls, pha, norm = model.to_spectro(lr, mask=True)
+            n_enc = len(draws)
+            aud = None
+            if not opt.explicit_encoding:
+                aud = model.to_audio(ls.float(), {k: v.float() for k, v in norm.items() if k in ("max", "min")}, pha.float())
+        finally:
+            for k, v in real.items():
+                setattr(torch, k, v)
+        d[f"{name}_spectro"] = _np(ls); d[f"{name}_pha"] = _np(pha)
+        d[f"{name}_max"] = _np(norm["max"]); d[f"{name}_min"] = _np(norm["min"])
+        d[f"{name}_draw_kinds"] = np.array([k for k, _ in draws])
+        d[f"{name}_n_encode_draws"] = np.array(n_enc)
+        for i, (_, t) in enumerate(draws):
+            d[f"{name}_draw{i}"] = _np(t)
+        if aud is not None:
+            d[f"{name}_audio"] = _np(aud)
+        print(name, tuple(ls.shape), [k for k, _ in draws])
+    np.savez_compressed(os.path.join(out, "spectro_modes.npz"), **d)
+    print("spectro_modes.npz", len(d), "arrays")
+
+
 def gen_evaltail(out):
     """util.imdct + compute_matrics (util/util.py:104-184) as generate_audio.py:40-49 calls them."""
     import util.util as U
@@ -472,6 +551,8 @@ def main():
         gen_networks_d3(a.out)
     if "model" in todo:
         gen_model(a.out)
+    if "spectro_modes" in todo:
+        gen_spectro_modes(a.out)
     if "evaltail" in todo:
         gen_evaltail(a.out)
     if "feeder" in todo:
