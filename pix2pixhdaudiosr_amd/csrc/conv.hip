@@ -159,6 +159,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     }
   }
   __syncthreads();
+#ifdef P2PHD_PROBE_FINE
+  const unsigned long long pf_a = __builtin_readcyclecounter();
+#endif
 
   // Direct global -> LDS staging (buffer_load_dwordx4 ... lds): one wave instruction fills 8 consecutive 128-byte
   // tile rows linearly (lane l -> row l>>3, slot l&7).  The bank-conflict swizzle therefore sits on the SOURCE:
@@ -325,6 +328,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
     }
   }
+#ifdef P2PHD_PROBE_FINE
+  const unsigned long long pf_b = __builtin_readcyclecounter();
+#endif
   if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -409,11 +415,16 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   float oscale = 1.f;                                        // fp8: de-quantisation factor of the packed weights
   if constexpr (sizeof(T) == 1) oscale = *d.out_scale;
   char* ct = stages;
-  // the activation is chosen ONCE per tile (a per-element switch costs a dozen scalar branches per value and keeps
-  // the tanh expansion in every element's path): a straight-line instance for tanh, one for the slope family
+  // The epilogue is VALU-bound (64-192 accumulators per lane, two waves per SIMD), so its per-element work is chosen
+  // ONCE per tile: ACT = tanh | slope family (ReLU / LeakyReLU as one select) | identity (every layer that wants
+  // statistics: its activation runs after the normalisation), and FULL = every tile row is a pixel of the sample (no
+  // row masks in the sums; all tiles but a sample's last).  A per-element switch costs a dozen scalar branches per
+  // value and keeps the tanh expansion in every element's path.
   const float neg_slope = act == P2PHD_ACT_RELU ? 0.f : (act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
-  auto stage_tile = [&](auto act_tag) {
+  constexpr int ACT_IDENT = -1;
+  auto stage_tile = [&](auto act_tag, auto full_tag) {
     constexpr int ACT = decltype(act_tag)::value;
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int col = wn * (NR * 32) + j * 32 + lr;
@@ -431,9 +442,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
           const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
           if constexpr (sizeof(T) == 1) acc[i][j][e] *= oscale;
           float v = acc[i][j][e] + bv;
-          if (p_base + row < p_end) s1 += v;
+          if (FULL || p_base + row < p_end) s1 += v;
           if constexpr (ACT == P2PHD_ACT_TANH) v = tanhf(v);
-          else v = v > 0.f ? v : neg_slope * v;                // none / ReLU / LeakyReLU(0.2) as one select
+          else if constexpr (ACT != ACT_IDENT) v = v > 0.f ? v : neg_slope * v;   // none / ReLU / LeakyReLU(0.2) as one select
           *reinterpret_cast<TO*>(ct + row * CROW + col * (int)sizeof(TO)) = from_f<TO>(v);
         }
       }
@@ -444,7 +455,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         // |mean| / sigma up to 25 in front of the first InstanceNorm, which costs that formula 3 digits in fp32.
         s1 += __shfl_xor(s1, 32);
         const int first = p_base + wm * (MR * 32);
-        const int cnt = min(max(p_end - first, 0), MR * 32);
+        const int cnt = FULL ? MR * 32 : min(max(p_end - first, 0), MR * 32);
         const float mean_w = cnt > 0 ? s1 / (float)cnt : 0.f;
         float m2 = 0.f;
 #pragma unroll
@@ -453,7 +464,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
           for (int e = 0; e < 16; ++e) {
             const int row = wm * (MR * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
             const float dlt = acc[i][j][e] + bv - mean_w;
-            if (p_base + row < p_end) m2 += dlt * dlt;
+            if (FULL || p_base + row < p_end) m2 += dlt * dlt;
           }
         }
         m2 += __shfl_xor(m2, 32);
@@ -467,9 +478,30 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       }
     }
   };
-  if (act == P2PHD_ACT_TANH) stage_tile(std::integral_constant<int, P2PHD_ACT_TANH>{});
-  else stage_tile(std::integral_constant<int, P2PHD_ACT_NONE>{});
+  {
+    typedef std::true_type Y;
+    typedef std::false_type N_;
+    typedef std::integral_constant<int, P2PHD_ACT_TANH> Tanh;
+    typedef std::integral_constant<int, P2PHD_ACT_RELU> Slope;
+    typedef std::integral_constant<int, ACT_IDENT> Ident;
+    if constexpr (MR * NR <= 6) {
+      const bool full = p_base + BM <= p_end;
+      if (act == P2PHD_ACT_TANH) stage_tile(Tanh{}, N_{});
+      else if (act == P2PHD_ACT_NONE) { if (full) stage_tile(Ident{}, Y{}); else stage_tile(Ident{}, N_{}); }
+      else { if (full) stage_tile(Slope{}, Y{}); else stage_tile(Slope{}, N_{}); }
+    } else {
+      // the 128-accumulator tile keeps two instances: more straight-line copies cost it registers (it spills)
+      if (act == P2PHD_ACT_TANH) stage_tile(Tanh{}, N_{});
+      else stage_tile(Slope{}, N_{});
+    }
+  }
+#ifdef P2PHD_PROBE_FINE
+  const unsigned long long pf_c = __builtin_readcyclecounter();
+#endif
   __syncthreads();
+#ifdef P2PHD_PROBE_FINE
+  const unsigned long long pf_d = __builtin_readcyclecounter();
+#endif
   constexpr int CPR = BN / EPPO;                             // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   for (int q = tid; q < BM * CPR; q += NT) {
@@ -504,8 +536,15 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   if (tid == 0) {
     const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x) % kProbeSlots;
     unsigned long long* r = g_probe + (size_t)wg * 8;
+#ifdef P2PHD_PROBE_FINE
+    // prologue: table build | descriptor + fragment addresses + DMA issue | first wait + barrier + first fragments;
+    // epilogue: statistics + LDS staging | barrier | store loop (the barrier after the K loop is in the first)
+    r[0] += pf_a - pr_t0; r[1] += pf_b - pf_a; r[2] += pr_t1 - pf_b; r[3] += pr_t2 - pr_t1;
+    r[4] += pf_c - pr_t2; r[5] += pf_d - pf_c; r[6] += 1ull; r[7] += pr_t3 - pf_d;
+#else
     r[0] += pr_wait; r[1] += pr_bar; r[2] += pr_comp; r[3] += (unsigned long long)nsteps;
     r[4] += pr_t1 - pr_t0; r[5] += pr_t3 - pr_t2; r[6] += 1ull; r[7] += pr_t3 - pr_t0;
+#endif
   }
 #endif
 }
@@ -1386,12 +1425,15 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)
-    if (huge && force == 0 && fits3 && bn == 128) {
+    if (huge && force == 0 && (fits3 || fits2) && bn == 128) {
       // rounds x tile width: a 256-wide grid of 257..300 workgroups runs two rounds for barely more than one round of
       // work (the discriminator's 256-channel input gradient: 269 tiles); 128-wide tiles then cost less in total
       const long wg256 = mt256 * ((k + 255) / 256), wg128 = mt256 * ((k + 127) / 128);
       const double c256 = std::ceil(wg256 / 256.0) * 256.0, c128 = std::ceil(wg128 / 256.0) * 128.0 / 0.85;
-      if (c128 < c256) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+      if (c128 < c256) {
+        if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+        return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);   // 16-tap gather table
+      }
     }
     if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }

@@ -29,6 +29,11 @@ L.p2phd_debug_probe(buf, 1)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); call(); e1.record(); torch.cuda.synchronize()
 L.p2phd_debug_probe(buf, 1)
+if os.environ.get("FINE"):                                   # -DP2PHD_PROBE -DP2PHD_PROBE_FINE build
+    tb, setup, first, loop, stage, bar2, nw, store = (float(v) for v in buf[:8])
+    print(f"{' '.join(sys.argv[1:])}: {e0.elapsed_time(e1)*1e3:.0f} us; per workgroup (wave 0) cycles: table {tb/nw:.0f} | setup + DMA issue {setup/nw:.0f} | "
+          f"first wait {first/nw:.0f} | K loop {loop/nw:.0f} | statistics + LDS staging {stage/nw:.0f} | barrier {bar2/nw:.0f} | stores {store/nw:.0f}; workgroups {nw:.0f}")
+    sys.exit(0)
 wait, bar, comp, nst, pro, epi, nw, tot = (float(v) for v in buf[:8])
 print(f"{' '.join(sys.argv[1:])}: {e0.elapsed_time(e1)*1e3:.0f} us (fwd incl. stats pass); per workgroup (wave 0): total {tot/nw:.0f} cyc = "
       f"prologue {pro/nw:.0f} + loop {comp/nw:.0f} ({nst/nw:.0f} steps: wait {wait/nw:.0f}, barrier {bar/nw:.0f}) + epilogue {epi/nw:.0f}; workgroups {nw:.0f}")

@@ -13,6 +13,9 @@ CONFIGS = {
     "cfg3 G3L2_48ngf (opt.txt: local nd4 nbg3 nle1 nbl2) fp32 B4": (dict(netG="local", n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=False), 4),
     "cfg3' (BASELINE wording: local nd3 nb9 nle2 nbl3) bf16 B8": (dict(netG="local", n_downsample_global=3, n_blocks_global=9, n_local_enhancers=2, n_blocks_local=3), 8),
     "cfg5 n_fft2048 ngf64 local defaults num_D3 bf16 B4": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3), 4),
+    "cfg5 + fp8 (e4m3 forward of the wide stride-1 convs) B4": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3, fp8=True), 4),
+    "cfg5 bf16 B8": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3), 8),
+    "cfg5 + fp8 B8": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3, fp8=True), 8),
 }
 
 def main():
@@ -40,7 +43,8 @@ def main():
         vals = {k: round(float(v), 4) for k, v in ld.items()}
         ok = all(torch.isfinite(p).all() for p in model.parameters())
         nG = sum(p.numel() for p in model.netG.parameters())
-        print(f"{name}: {dt*1e3:.1f} ms/step, {B*frames/dt:.0f} frames/s, G params {nG}, finite={ok}, losses {vals}", flush=True)
+        extra = f", fp8 layers {model.fp8_layers}" if getattr(model, "fp8_layers", 0) else ""
+        print(f"{name}: {dt*1e3:.1f} ms/step, {B*frames/dt:.0f} frames/s, G params {nG}{extra}, finite={ok}, losses {vals}", flush=True)
         del model, ld
         import gc; gc.collect()
         torch.cuda.empty_cache()
