@@ -91,9 +91,6 @@ def _check_arena(ctx, device):
                                   "started before this backward ran (run backward before the next forward)")
 
 
-# measurement hook: `match(spec, N, H, W) -> bool` selects conv layers whose forward launch is bracketed by HIP events on
-# the launch stream (eager steps only); bench.py times the dominant kernel inside a real step this way
-_KERNEL_PROBE = {"match": None, "events": []}
 # debugging hook: when a list, every conv block's backward appends (spec, g, dy, gx) clones (tools only)
 _BWD_TRACE = [None]
 # number of forward convs that ran on the fp8 entry point (bench.py reports it with --fp8)
@@ -415,20 +412,11 @@ class ConvBlockFn(torch.autograd.Function):
         fused_act = ACT_NONE if spec.norm else spec.act
         wsb = L.p2phd_conv_fwd_workspace_bytes(C.byref(d))
         ws = workspace(wsb, x.device) if wsb else None
-        probe = _KERNEL_PROBE.get("match")
-        if probe is not None and probe(spec, N, H, W):              # bench.py: HIP events around this layer's launches
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        else:
-            e0 = None
         if x8 is not None:
             _FP8_CALLS[0] += 1
             check(L.p2phd_conv_fwd_fp8(C.byref(d), ptr(x8), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd_fp8")
         else:
             check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
-        if e0 is not None:
-            e1.record()
-            _KERNEL_PROBE["events"].append((e0, e1))
         if spec.norm:
             res = None if residual is None else phys(residual, "residual")
             out = empty_like(y)
