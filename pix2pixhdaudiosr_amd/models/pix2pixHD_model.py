@@ -541,7 +541,14 @@ class Pix2PixHDModel(BaseModel):
         self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
 
     def update_fixed_params(self):
+        """pix2pixHD_model.py:521-528: after niter_fix_global epochs the global generator trains too -- a fresh Adam over
+        every generator parameter (the reference resets the optimiser state as well).  Graphs captured with the old
+        optimiser's buffers are dropped; data-parallel settings carry over."""
+        old = self.optimizer_G
         self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        if getattr(old, '_collectives', False) or old.world_size > 1:
+            self.optimizer_G.enable_data_parallel(old.world_size, old.process_group, getattr(old, '_collectives', False) and old.world_size == 1)
+        self._graph_state = None
         if _opt(self.opt, 'verbose', False):
             print('------------ Now also finetuning global generator -----------')
 
