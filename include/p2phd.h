@@ -163,6 +163,20 @@ size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const void* packed_dgrad, const void* addend, void* dx,
                      void* workspace, void* stream);
 
+/* Input gradient with the FIRST pass of the producer's InstanceNorm backward fused into its store loop (round 2).  dx is
+ * the gradient of the tensor this conv read, which a previous layer produced as act(InstanceNorm(prev_y)); prev_y
+ * [N,H,W,Cp(C)] are that layer's pre-normalisation values, prev_stats [N,Cp(C),2] its (mean, M2) statistics, prev_act its
+ * activation (NONE / RELU / LRELU).  Besides dx (+ addend) the call leaves bstats [N,Cp(C),2] = per (n, c)
+ * (sum g', sum g' * yhat), g' = dx * act'(yhat) -- exactly what p2phd_instnorm_act_bwd's reduce pass computes from (dx,
+ * prev_y) in two more tensor reads -- summed in a fixed order (no atomics).  Feed it to p2phd_instnorm_act_bwd_apply.
+ * Available when p2phd_conv_dgrad_bsum_ok(desc) (one direct gather-GEMM launch: no reflect padding, no W-fold, not the
+ * dedicated 7x7 kernel); workspace: p2phd_conv_dgrad_bsum_workspace_bytes (this call does not need the plain dgrad workspace). */
+int p2phd_conv_dgrad_bsum_ok(const p2phd_conv_desc* c);
+size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c);
+int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, const void* packed, const void* addend, void* dx,
+                          const void* prev_y, const float* prev_stats, int prev_act, float eps, float* bstats,
+                          void* workspace, void* stream);
+
 /* dw (master layout, f32, overwritten) and db (f32 [K], overwritten, may be NULL) from x and dy. */
 size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, void* workspace,
@@ -192,6 +206,12 @@ int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, const float*
 /* Same, with db += instead of db = (see p2phd_conv_wgrad_acc). */
 int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
                                float* db, int N, int64_t HW, int C, float eps, int act, void* stream);
+/* The second (apply) pass alone, with the sums already in bstats (p2phd_conv_dgrad_bsum); db_accumulate != 0 adds the bias
+ * gradient into db instead of overwriting it.  Only for planes that take the two-pass form:
+ * p2phd_instnorm_act_bwd_two_pass(dtype, N, HW, C) != 0 (small planes use a single register-resident launch). */
+int p2phd_instnorm_act_bwd_two_pass(int dtype, int N, int64_t HW, int C);
+int p2phd_instnorm_act_bwd_apply(int dtype, const void* g, const void* y, const float* stats, const float* bstats, void* dy,
+                                 float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */
 int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream);
 /* Same over [n_pixels][Cp] tensors, plus db[c] (+)= sum over pixels of dx[., c]: the conv bias gradient of a layer with a

@@ -45,6 +45,9 @@ SIGNATURES = {
     "p2phd_conv_fwd_fp8": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "p2phd_conv_dgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_dgrad_bsum_ok": (_i32, [_vp]),
+    "p2phd_conv_dgrad_bsum_workspace_bytes": (_sz, [_vp]),
+    "p2phd_conv_dgrad_bsum": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_wgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_wgrad_acc": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -52,6 +55,8 @@ SIGNATURES = {
     "p2phd_instnorm_act_fwd_q8": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
+    "p2phd_instnorm_act_bwd_two_pass": (_i32, [_i32, _i32, _i64, _i32]),
+    "p2phd_instnorm_act_bwd_apply": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "p2phd_act_bwd_db": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
     "p2phd_avgpool3s2_fwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),

@@ -95,6 +95,8 @@ def _check_arena(ctx, device):
 _BWD_TRACE = [None]
 # number of forward convs that ran on the fp8 entry point (bench.py reports it with --fp8)
 _FP8_CALLS = [0]
+# number of InstanceNorm backward passes that took the sums from the consumer's input-gradient kernel
+_BSUM_CALLS = [0]
 
 
 # parameters whose weight gradient is not wanted by the backward pass that is running right now (a retained graph
@@ -315,6 +317,7 @@ class ToPhysical(torch.autograd.Function):
 class FromPhysical(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_phys, channels):
+        _note_consumer(x_phys)
         ctx.meta = (x_phys.dtype, x_phys.shape[-1])
         return from_physical(x_phys, channels)
 
@@ -393,9 +396,34 @@ class ConvSpec:
         return buf
 
 
+# Fused first pass of the producer's InstanceNorm backward (p2phd_conv_dgrad_bsum): when the tensor a conv block reads is the
+# output of an InstanceNorm block and NOBODY ELSE consumes it, the block's input-gradient kernel also leaves the
+# per-(n, c) sums that block's backward needs, and it then runs the apply pass only -- one pass over (g, y) less on the big
+# planes.  "Nobody else" cannot be inferred: autograd sums the contributions of several consumers into one tensor, in
+# place and without a version bump when it owns the buffer, so neither pointer nor version of the gradient proves it.
+# The CALLER states it: conv_block(..., exclusive=True) is passed by networks._run for a step whose input is the
+# previous step's output and leaves the chain nowhere else (the generator's sequential chains; never the
+# discriminator's exposed features).  Pointer, version and a consumer count of the Functions of this module are kept as
+# secondary guards.  P2PHD_BSUM=0 switches the fusion off (A/B runs).
+def _bsum_enabled():
+    return os.environ.get("P2PHD_BSUM", "1") != "0"
+
+
+def _note_consumer(t):
+    gf = getattr(t, "grad_fn", None)
+    if gf is not None and hasattr(gf, "_p2phd_consumers"):
+        gf._p2phd_consumers += 1
+    return gf
+
+
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec, link=None):
+    def forward(ctx, x, weight, bias, residual, spec, link=None, exclusive=False):
+        src = _note_consumer(x)
+        if not exclusive:
+            src = None
+        if residual is not None:
+            _note_consumer(residual)
         x = phys(x, "conv input")
         N, H, W, Cp_in = x.shape
         if Cp_in != cpitch(spec.cin):
@@ -439,6 +467,10 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.x, ctx.y, ctx.stats, ctx.weight, ctx.bias = x, y, stats, weight, bias
         ctx.link = link
         ctx.arena_gen = arena_generation(x.device) if spec.norm else 0
+        ctx._p2phd_consumers = 0                                   # forward calls that read `out` (see _note_consumer)
+        ctx._bs = None                                             # (bstats, data_ptr, version) left by the consumer's dgrad
+        ctx.src = src if (src is not None and hasattr(src, "_p2phd_consumers") and getattr(src, "spec", None) is not None
+                          and src.spec.norm) else None
         return out
 
     @staticmethod
@@ -462,11 +494,18 @@ class ConvBlockFn(torch.autograd.Function):
         gb_done = False
         if spec.norm:
             dy = empty_like(y)
-            bstats = empty((N, Cp_out, 2), torch.float32, y.device)
-            # the bias gradient (column sums of dy) rides on the apply pass
-            bwd = L.p2phd_instnorm_act_bwd_acc if direct else L.p2phd_instnorm_act_bwd
-            check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
-                      stream_ptr()), "instnorm_act_bwd")
+            bs, ctx._bs = ctx._bs, None
+            if bs is not None and g.data_ptr() == bs[1] and g._version == bs[2] and g.shape == y.shape:
+                # the consumer's input-gradient kernel already summed (g', g' * yhat): apply pass only
+                check(L.p2phd_instnorm_act_bwd_apply(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bs[0]), ptr(dy), ptr(gb), 1 if direct else 0,
+                                                     N, Ho * Wo, spec.cout, IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd_apply")
+                _BSUM_CALLS[0] += 1
+            else:
+                bstats = empty((N, Cp_out, 2), torch.float32, y.device)
+                # the bias gradient (column sums of dy) rides on the apply pass
+                bwd = L.p2phd_instnorm_act_bwd_acc if direct else L.p2phd_instnorm_act_bwd
+                check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
+                          stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
         elif spec.act != ACT_NONE:
             dy = empty_like(y)
@@ -505,13 +544,26 @@ class ConvBlockFn(torch.autograd.Function):
             addend = None
             if ctx.link is not None and ctx.link.role_of(ctx) == "a":
                 addend = ctx.link.take()
-            check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
+            src = ctx.src
+            fuse = (src is not None and src._p2phd_consumers == 1 and _bsum_enabled() and src.y is not None
+                    and src.y.shape == x.shape and src.y.dtype == x.dtype and src.spec.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+                    and L.p2phd_instnorm_act_bwd_two_pass(d.dtype, x.shape[0], x.shape[1] * x.shape[2], spec.cin)
+                    and L.p2phd_conv_dgrad_bsum_ok(C.byref(d)))
+            if fuse:
+                _check_arena(src, y.device)
+                bst = empty((x.shape[0], x.shape[3], 2), torch.float32, y.device)
+                wsf = workspace(max(L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 256), y.device)
+                check(L.p2phd_conv_dgrad_bsum(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src.y), ptr(src.stats),
+                                              src.spec.act, IN_EPS, ptr(bst), ptr(wsf), stream_ptr()), "conv_dgrad_bsum")
+                src._bs = (bst, gx.data_ptr(), gx._version)
+            else:
+                check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
         if _BWD_TRACE[0] is not None:
             _BWD_TRACE[0].append((spec, g.detach().clone(), dy.detach().clone(), None if gx is None else gx.detach().clone()))
         gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
         if gres is not None and ctx.link is not None and ctx.link.park(gres, ctx):
             gres = None
-        return gx, gw, gb, gres, None, None
+        return gx, gw, gb, gres, None, None, None
 
 
 class SkipLink:
@@ -537,10 +589,11 @@ class SkipLink:
         return g
 
 
-def conv_block(x, weight, bias, spec, residual=None, link=None):
+def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False):
+    """`exclusive`: x is the output of another conv_block and this call is its ONLY consumer (see _bsum_enabled)."""
     if link is not None and residual is None:
         link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
-    out = ConvBlockFn.apply(x, weight, bias, residual, spec, link)
+    out = ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive)
     if spec._q8_out is not None:                                    # e4m3 twin of this output for the next layer's fp8 forward
         out._p2phd_q8, spec._q8_out = spec._q8_out, None
     return out
@@ -583,6 +636,7 @@ class LossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, kind, target, coeff, channels):
+        _note_consumer(a)
         a = phys(a, "loss input")
         P = a.numel() // a.shape[-1]
         out = zeros((), a.device)

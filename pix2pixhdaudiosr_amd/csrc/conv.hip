@@ -504,6 +504,91 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
   constexpr int CPR = BN / EPPO;                             // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
+  if constexpr (MR * NR <= 6 && sizeof(T) != 1) {
+    if (d.bs_out != nullptr) {
+      // Store loop with the consumer's InstanceNorm-backward sums riding on it (GDesc::bs_out).  A thread keeps ONE
+      // piece column (8 / 4 channels) for all its rows, so the channel constants are loaded once and the sums stay in
+      // registers; they are folded over the threads of a column through LDS in a fixed order (no atomics) and leave as
+      // this tile's row of the partial table.
+      constexpr int RG = NT / CPR;                           // threads per piece column (the last NT % CPR threads idle)
+      const int pcb = tid % CPR, rgb = tid / CPR;
+      const int kb = n0 + pcb * EPPO;
+      int kch = kb, clsb = 0;
+      if (cls_cp > 0) { clsb = (kb >= cls_cp) + (kb >= 2 * cls_cp) + (kb >= 3 * cls_cp); kch = kb - clsb * cls_cp; }
+      const bool col_ok = kb < n_extent && rgb < RG;
+      float a1[EPPO], a2[EPPO], mean_b[EPPO], rstd_b[EPPO];
+#pragma unroll
+      for (int e = 0; e < EPPO; ++e) {
+        a1[e] = a2[e] = 0.f;
+        const bool ch_ok = col_ok && kch + e < Kout;
+        const float2 ms = ch_ok ? *reinterpret_cast<const float2*>(d.bs_stats + 2 * ((size_t)n * Cp_out + kch + e)) : make_float2(0.f, 0.f);
+        mean_b[e] = ms.x;
+        rstd_b[e] = ch_ok ? rsqrtf(fmaxf(ms.y * d.bs_inv_hw, 0.f) + d.bs_eps) : 0.f;
+      }
+      const TO* bsy = reinterpret_cast<const TO*>(d.bs_y);
+      const float slope_b = d.bs_slope;
+      if (col_ok) {
+        // U rows at a time: their pre-normalisation pieces (and addends) are all requested before the first one is used --
+        // a load consumed in the iteration that issues it costs a memory round trip per row
+        constexpr int U = 4;
+        for (int row0 = rgb; row0 < BM; row0 += RG * U) {
+          uint4 yv[U], av[U];
+          size_t opx[U];
+          bool ok[U];
+          int rowu[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int row = row0 + u * RG;
+            rowu[u] = min(row, BM - 1);
+            const int2 ri = rinfo[rowu[u]];
+            int ho = ri.y >> 16, wo = ri.y & 0xFFFF;
+            ok[u] = row < BM && ri.x >= 0;
+            if (cls_cp > 0) {
+              ho = 2 * ho + (clsb >> 1); wo = 2 * wo + (clsb & 1);
+              ok[u] = ok[u] && ho < Hout && wo < Wout;
+            }
+            opx[u] = ok[u] ? ((size_t)ri.x * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo) : 0;   // clamped: always loadable
+            yv[u] = *reinterpret_cast<const uint4*>(bsy + opx[u] * Cp_out + kch);
+            if (addend != nullptr) av[u] = *reinterpret_cast<const uint4*>(addend + opx[u] * Cp_out + kch);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(ct + rowu[u] * CROW + pcb * 16);
+            if (addend != nullptr) {
+              TO* vv = reinterpret_cast<TO*>(&v);
+              const TO* aa = reinterpret_cast<const TO*>(&av[u]);
+#pragma unroll
+              for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) + to_f(aa[e]));
+            }
+            *reinterpret_cast<uint4*>(out + opx[u] * Cp_out + kch) = v;
+            const TO* gg = reinterpret_cast<const TO*>(&v);      // the ROUNDED gradient: what the apply pass will read
+            const TO* yy = reinterpret_cast<const TO*>(&yv[u]);
+#pragma unroll
+            for (int e = 0; e < EPPO; ++e) {
+              const float yh = (to_f(yy[e]) - mean_b[e]) * rstd_b[e];
+              const float gp = to_f(gg[e]) * (yh > 0.f ? 1.f : slope_b);
+              a1[e] += gp; a2[e] += gp * yh;
+            }
+          }
+        }
+      }
+      __syncthreads();                                        // every thread is done with the C tile
+      float* red = reinterpret_cast<float*>(ct);              // [NT][2 * EPPO]
+#pragma unroll
+      for (int e = 0; e < EPPO; ++e) { red[tid * (2 * EPPO) + e] = a1[e]; red[tid * (2 * EPPO) + EPPO + e] = a2[e]; }
+      __syncthreads();
+      const int tile_in_sample = blockIdx.x - n * mtiles;
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int col = t >> 1, which = t & 1, pc = col / EPPO, e = col - pc * EPPO;
+        float sum = 0.f;
+        for (int rg = 0; rg < RG; ++rg) sum += red[(rg * CPR + pc) * (2 * EPPO) + which * EPPO + e];
+        if (n0 + col < n_extent)
+          d.bs_out[(((size_t)n * mtiles + tile_in_sample) * n_extent + n0 + col) * 2 + which] = sum;
+      }
+      return;
+    }
+  }
   for (int q = tid; q < BM * CPR; q += NT) {
     const int row = q / CPR, pc = q - row * CPR;
     int k = n0 + pc * EPPO;
@@ -1354,7 +1439,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   GDesc d = d_in;
   // InstanceNorm partials: one slot per wave row block (MR * 32 rows) of a sample, see the epilogue
   d.stats_slots = (d.Hg * d.Wg + MR * 32 - 1) / (MR * 32);
-  if (slot_rows) *slot_rows = MR * 32;
+  if (slot_rows) *slot_rows = d.bs_out != nullptr ? BM : MR * 32;   // (fused backward sums: one partial per TILE)
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int CT = BM * (BN * (int)sizeof(typename OutOf<T>::type) + 16);
   const int tab = ((d.nth * d.ntw * BM * 4 + 15) & ~15) + BM * 8;        // gather table + row table
@@ -1388,7 +1473,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   const int taps = d.nth * d.ntw;
   // 256-row tiles (8 waves, 3-slot ring) halve the weight traffic per FLOP: used when a sample has enough pixels to
   // fill them, the grid still covers the chip, and ring + gather table fit the 160 KiB of LDS
-  d.flat_m = stats == nullptr && (npix % 256 != 0);          // no InstanceNorm sums wanted: tiles may straddle samples
+  d.flat_m = stats == nullptr && d.bs_out == nullptr && (npix % 256 != 0);   // no per-sample sums wanted: tiles may straddle samples
   const long mt256 = d.flat_m ? ((long)d.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d.N;
   const long tabb = (long)taps * 256 * 4 + 16 + 256 * 8;
   const long kLds = 160 * 1024;
@@ -1397,6 +1482,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // grid still fills most of the chip.  256 x {128,64}: 3-slot ring when it fits beside the gather table, else 2-slot.
   const bool fits_huge = sizeof(T) == 2 && 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
   bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
+  if (d.bs_out != nullptr) huge = false;                     // (the 128-accumulator tile has no fused-sums store loop)
   const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
   const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(typename OutOf<T>::type) + 16) + tabb <= kLds;
   // short reductions (<= 4 K steps: the folded 2-channel layers, the 4-channel D input) are all prologue and epilogue:
@@ -1406,7 +1492,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   const int force = p2phd::g_opt_gconv_bm;
   if (force == 128) { big = false; huge = false; }
   if (force == 256) { big = fits3 || fits2; huge = false; }
-  if (force == 512) { huge = fits_huge && k > 128; }
+  if (force == 512) { huge = fits_huge && k > 128 && d.bs_out == nullptr; }
   // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
   if (force == 192 && sizeof(T) <= 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
@@ -1450,9 +1536,36 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
 }
 
+// bstats[n][c] = sum over tiles (and sub-pixel classes) of the partials one input-gradient launch left (GDesc::bs_out):
+// one wavefront per (sample, channel), lanes over tiles, fixed shuffle tree -> the result does not depend on timing
+__global__ __launch_bounds__(256) void bsum_merge_kernel(const float* __restrict__ part, float* __restrict__ bstats, int tiles,
+                                                         int n_extent, int cls_cp, int Cp, int C) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
+  if (c >= C) return;
+  const int ncls = cls_cp > 0 ? 4 : 1;
+  float s1 = 0.f, s2 = 0.f;
+  for (int t = lane; t < tiles; t += 64)
+    for (int q = 0; q < ncls; ++q) {
+      const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)n * tiles + t) * n_extent + q * cls_cp + c) * 2);
+      s1 += v.x; s2 += v.y;
+    }
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) *reinterpret_cast<float2*>(bstats + 2 * ((size_t)n * Cp + c)) = make_float2(s1, s2);
+}
+
 }  // namespace
 
 namespace p2phd {
+
+int launch_bsum_merge(const float* table, float* bstats, int N, long npix, int tile_rows, int n_extent, int cls_cp, int Cp, int C,
+                      hipStream_t st) {
+  const int tiles = (int)((npix + tile_rows - 1) / tile_rows);
+  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);       // pad channels read as zero
+  hipLaunchKernelGGL(bsum_merge_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)N), dim3(256), 0, st, table, bstats, tiles, n_extent,
+                     cls_cp, Cp, C);
+  return check_launch("bsum_merge");
+}
 
 int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, const float* bias, const void* addend,
                  void* out, float* stats, hipStream_t st, int* slot_rows) {

@@ -497,6 +497,52 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
   return P2PHD_OK;
 }
 
+// ---- input gradient with the consumer's InstanceNorm-backward sums fused into its store loop -------------------------
+namespace {
+// one plain or merged sub-pixel gather-GEMM launch writing dx directly (no reflect fold, no W-fold, not the 7x7 kernel),
+// on a tile shape that has the fused store loop (gconv 256x256 does not: see launch_gconv_t)
+bool dgrad_bsum_plans(const p2phd_conv_desc* c, std::vector<Plan>& plans) {
+  if (check_desc(c) != P2PHD_OK || c->N == 0) return false;
+  if (c->pad_mode == 1 || fold_mode(c) == FOLD_OUT || c7_out_dgrad_ok(c)) return false;
+  WMap m;
+  make_plans(c, 1, plans, &m);
+  return plans.size() == 1;
+}
+}  // namespace
+
+extern "C" int p2phd_conv_dgrad_bsum_ok(const p2phd_conv_desc* c) {
+  std::vector<Plan> plans;
+  return dgrad_bsum_plans(c, plans) ? 1 : 0;
+}
+
+extern "C" size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c) {
+  std::vector<Plan> plans;
+  if (!dgrad_bsum_plans(c, plans)) return 0;
+  return align256(bsum_table_floats(plans[0].d) * sizeof(float));
+}
+
+extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, const void* wp, const void* addend, void* dx,
+                                     const void* prev_y, const float* prev_stats, int prev_act, float eps, float* bstats,
+                                     void* workspace, void* stream) {
+  std::vector<Plan> plans;
+  P2PHD_REQUIRE(dgrad_bsum_plans(c, plans), "conv_dgrad_bsum: this layer's input gradient has no fused-sums form (p2phd_conv_dgrad_bsum_ok)");
+  P2PHD_REQUIRE(dy && wp && dx && prev_y && prev_stats && bstats && workspace, "conv_dgrad_bsum: null pointer");
+  P2PHD_REQUIRE(prev_act == P2PHD_ACT_NONE || prev_act == P2PHD_ACT_RELU || prev_act == P2PHD_ACT_LRELU, "conv_dgrad_bsum: activation %d", prev_act);
+  hipStream_t st = (hipStream_t)stream;
+  Plan& p = plans[0];
+  p.d.bs_y = prev_y;
+  p.d.bs_stats = prev_stats;
+  p.d.bs_out = static_cast<float*>(workspace);
+  p.d.bs_inv_hw = 1.f / ((float)c->H * (float)c->W);            // dx has the conv INPUT's geometry [N, H, W, C]
+  p.d.bs_eps = eps;
+  p.d.bs_slope = prev_act == P2PHD_ACT_RELU ? 0.f : (prev_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+  const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
+  int tile_rows = 0;
+  if (int rc = launch_gconv(p.d, c->dtype, dy, w, nullptr, addend, dx, nullptr, st, &tile_rows)) return rc;
+  const int n_extent = p.d.n_extent ? p.d.n_extent : p.d.Cp_out;
+  return launch_bsum_merge(p.d.bs_out, bstats, c->N, (long)p.d.Hg * p.d.Wg, tile_rows, n_extent, p.d.cls_cp, cpitch(c->C), c->C, st);
+}
+
 namespace {
 // everything p2phd_conv_wgrad needs, derived once for both the workspace query and the call
 struct WgradSetup { Plan p; WMap m; int M; int Cp_r; int fold; size_t dwp_bytes; };

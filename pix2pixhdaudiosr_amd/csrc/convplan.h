@@ -21,6 +21,14 @@ struct GDesc {
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
   int stats_slots;                            // slots per sample of the statistics table (set by the launcher)
   const float* out_scale;                     // fp8 operands: device pointer to the weights' de-quantisation factor
+  // Fused first pass of the CONSUMER's InstanceNorm backward (input-gradient launches only): the tensor written here is
+  // the gradient g of an InstanceNorm + activation output whose pre-normalisation values are bs_y (same shape as the
+  // written tensor) with statistics bs_stats [N][Cp_out][2] = (mean, M2).  Every tile leaves its partial
+  // (sum g', sum g' * yhat) per column in bs_out [N][tiles per sample][n_extent][2]; launch_bsum_merge folds them.
+  const void* bs_y;
+  const float* bs_stats;
+  float* bs_out;                              // nullptr = off
+  float bs_inv_hw, bs_eps, bs_slope;          // 1 / pixels per plane, eps, negative slope of the activation (1 = none)
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -81,6 +89,14 @@ inline size_t stat_table_floats(const GDesc& d) {
 }
 // stats[n][c] = (mean, sum of squared deviations) over the sample's plane, merged from `slots` partials per class in a
 // fixed order (Chan et al.); slot s holds rows [s * slot_rows, (s+1) * slot_rows) of the npix rows of a sample.
+// partial table of the fused InstanceNorm-backward sums (see GDesc::bs_out): floats needed for any tile height >= 128,
+// and the merge into bstats [N][Cp][2]; `tile_rows` = the BM the launch used (returned through launch_gconv's slot_rows)
+inline size_t bsum_table_floats(const GDesc& d) {
+  const size_t tiles = ((size_t)d.Hg * d.Wg + 127) / 128;
+  return (size_t)d.N * tiles * (size_t)(d.n_extent ? d.n_extent : d.Cp_out) * 2;
+}
+int launch_bsum_merge(const float* table, float* bstats, int N, long npix, int tile_rows, int n_extent, int cls_cp, int Cp, int C,
+                      hipStream_t st);
 int launch_stats_merge(const float* table, float* stats, int N, int slots, int ncls, int Cp, int C, long npix, int slot_rows,
                        hipStream_t st);
 size_t wgrad_workspace_floats(const GDesc& d, int dtype, int M_rows, int M_rows_pad);

@@ -690,8 +690,21 @@ extern "C" int p2phd_instnorm_act_fwd_q8(int dtype, const void* y, const float* 
   return instnorm_act_fwd_impl(dtype, y, stats, residual, out, out8, N, HW, C, eps, act, stream);
 }
 
+// planes small enough (and numerous enough) for the single-launch register-resident backward
+static bool bwd_single_launch(int dtype, int N, int64_t HW, int C) {
+  const int Cp = (C + 7) & ~7;
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const int cblocks4 = (Cp / epp + 3) / 4;
+  return HW <= 640 && (long)N * cblocks4 >= 128;
+}
+
+extern "C" int p2phd_instnorm_act_bwd_two_pass(int dtype, int N, int64_t HW, int C) {
+  return (N > 0 && HW > 0 && !bwd_single_launch(dtype, N, HW, C)) ? 1 : 0;
+}
+
 static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
-                                 float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream) {
+                                 float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream,
+                                 bool sums_given = false) {
   const int Cp = (C + 7) & ~7;
   P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
   if (N == 0 || HW == 0) return P2PHD_OK;
@@ -702,7 +715,8 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   // small planes with enough (sample, channel block) pairs to fill the chip: single-launch register-resident variant;
   // 4 piece columns x 64 slices per workgroup when that still leaves <= 10 iterations (planes <= 640 pixels)
   const int cblocks4 = (Cp / epp + 3) / 4;
-  if (HW <= 640 && (long)N * cblocks4 >= 128) {
+  P2PHD_REQUIRE(!sums_given || !bwd_single_launch(dtype, N, HW, C), "instnorm_act_bwd_apply: this plane takes the single-launch backward (p2phd_instnorm_act_bwd_two_pass)");
+  if (bwd_single_launch(dtype, N, HW, C)) {
     dim3 fgrid((unsigned)cblocks4, (unsigned)N);
 #define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db)
     if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 8); else P2PHD_FUSED_BWD(bf16_t, 10); }
@@ -711,13 +725,15 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
 #undef P2PHD_FUSED_BWD
     return p2phd::check_launch("instnorm_act_bwd(fused)");
   }
-  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
   dim3 grid(stationary_grid(HW, Cp / epp, N), N);
+  if (!sums_given) {
+  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act),
              hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act),
              "instnorm_act_bwd");
   if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
+  }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act, db),
              hipLaunchKernelGGL(in_act_bwd_apply_kernel<float>, grid, dim3(256), Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (float*)dy, (long)HW, C, Cp, eps, act, db),
@@ -733,6 +749,12 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
 extern "C" int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
                                           float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
   return instnorm_act_bwd_impl(dtype, g, y, stats, bstats, dy, db, 1, N, HW, C, eps, act, stream);
+}
+
+extern "C" int p2phd_instnorm_act_bwd_apply(int dtype, const void* g, const void* y, const float* stats, const float* bstats,
+                                            void* dy, float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act,
+                                            void* stream) {
+  return instnorm_act_bwd_impl(dtype, g, y, stats, const_cast<float*>(bstats), dy, db, db_accumulate, N, HW, C, eps, act, stream, true);
 }
 
 extern "C" int p2phd_act_bwd(int dtype, const void* g, const void* a, void* dx, int64_t n_elems, int act, void* stream) {

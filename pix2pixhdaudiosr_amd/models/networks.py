@@ -105,8 +105,8 @@ class _ConvStep:
     def __init__(self, conv, spec):
         self.conv, self.spec = conv, spec
 
-    def run(self, x, residual=None, link=None):
-        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link)
+    def run(self, x, residual=None, link=None, exclusive=False):
+        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link, exclusive)
 
 
 class _ResStep:
@@ -114,10 +114,11 @@ class _ResStep:
         self.a, self.b = _compile(block.conv_block)
         assert isinstance(self.a, _ConvStep) and isinstance(self.b, _ConvStep)
 
-    def run(self, x, residual=None):
+    def run(self, x, residual=None, exclusive=False):
         assert residual is None
         link = _ops.SkipLink()                              # skip-path gradient is added inside conv a's dgrad
-        return self.b.run(self.a.run(x, link=link), residual=x, link=link)   # x + conv_block(x), reference networks.py:252
+        # x is read twice (conv a and the skip): never exclusive; a's output goes to b alone
+        return self.b.run(self.a.run(x, link=link), residual=x, link=link, exclusive=True)   # x + conv_block(x), reference networks.py:252
 
 
 def _compile(seq):
@@ -208,7 +209,9 @@ def _run(steps, x, residual_last=None, cuts=None, cut_after=()):
     """Run fused steps in order.  `cuts` (a list) collects the output of every step whose index is in `cut_after`: the
     points where the staged backward of the data-parallel step hands over (Pix2PixHDModel._phase_a)."""
     for j, s in enumerate(steps):
-        x = s.run(x, residual_last if j == len(steps) - 1 else None)
+        # from the second step on, the input is the previous step's output and is consumed here only (a cut tensor is an
+        # endpoint of torch.autograd.grad, not a consumer): the step may fuse the producer's backward sums (_ops)
+        x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0)
         if cuts is not None and j in cut_after:
             cuts.append(x)
     return x

@@ -371,3 +371,77 @@ def test_trunk_layer_at_baseline_size():
         y32 = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, x32), wd.detach(), bd.detach(), spec), cout)
     assert tuple(y32.shape) == (32, cout, 32, 16) and torch.isfinite(y32).all()
     assert rel_err(y32[:4].float().cpu().numpy(), yo.detach().numpy()) < 3e-2
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide"])
+def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, tol, monkeypatch):
+    """p2phd_conv_dgrad_bsum: the input-gradient kernel of the consumer leaves the (sum g', sum g' yhat) of the producer's
+    InstanceNorm backward, which then runs its apply pass only.  Same gradients as the two-pass form (P2PHD_BSUM=0) up to
+    the summation order of the statistics, for the plain launch, the merged sub-pixel launch (stride-2 conv) and the
+    stride-2 gather (transposed conv), and against the fp32 oracle."""
+    from pix2pixhdaudiosr_amd import _ops
+    N, C0, C1, H, W = 2, 16, 24, 48, 40                            # producer plane 48 x 40 = 1920 px: the two-pass form
+    if consumer == "s1_256wide":
+        C1 = 256
+    c2 = {"s2_conv": (C1, 32, 3, 2, 1, 0, False, 0), "s1_conv": (C1, 40, 3, 1, 1, 0, False, 0),
+          "conv_transpose": (C1, 16, 3, 2, 1, 0, True, 1), "s1_256wide": (C1, 256, 3, 1, 1, 0, False, 0)}[consumer]
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C0, H, W, generator=g)
+    w1 = torch.randn(C1, C0, 3, 3, generator=g) * 0.1
+    w2 = torch.randn((c2[0], c2[1], 3, 3) if c2[6] else (c2[1], c2[0], 3, 3), generator=g) * 0.05
+    specP = _ops.ConvSpec(C0, C1, 3, 1, 1, 0, False, 0, True, _ops.ACT_RELU)
+    specL = _ops.ConvSpec(*c2, True, _ops.ACT_RELU)
+
+    def run(flag):
+        monkeypatch.setenv("P2PHD_BSUM", flag)
+        xd = x.cuda().requires_grad_(True)
+        w1d, w2d = w1.cuda().requires_grad_(True), w2.cuda().requires_grad_(True)
+        h = _ops.conv_block(_ops.ToPhysical.apply(dtype, xd), w1d, None, specP)
+        o = _ops.conv_block(h, w2d, None, specL, exclusive=True)   # h goes nowhere else
+        out = _ops.FromPhysical.apply(o, c2[1])
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(5)).cuda()
+        n0 = _ops._BSUM_CALLS[0]
+        out.backward(cot)
+        torch.cuda.synchronize()
+        return out.detach().float().cpu(), xd.grad.cpu(), w1d.grad.cpu(), w2d.grad.cpu(), _ops._BSUM_CALLS[0] - n0
+
+    o1, gx1, gw1, gv1, used = run("1")
+    o0, gx0, gw0, gv0, unused = run("0")
+    assert used == 1 and unused == 0
+    assert torch.equal(o1, o0)
+    assert rel_err(gv1.numpy(), gv0.numpy()) < tol                 # (the consumer's own two-pass backward sums with float atomics)
+    assert rel_err(gx1.numpy(), gx0.numpy()) < tol and rel_err(gw1.numpy(), gw0.numpy()) < tol
+    if dtype == torch.float32:                                     # and against the oracle
+        xr, w1r, w2r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        hr = F.relu(F.instance_norm(F.conv2d(xr, w1r, padding=1), eps=1e-5))
+        if c2[6]:
+            orr = F.conv_transpose2d(hr, w2r, stride=2, padding=1, output_padding=1)
+        else:
+            orr = F.conv2d(hr, w2r, stride=c2[3], padding=1)
+        orr = F.relu(F.instance_norm(orr, eps=1e-5))
+        orr.backward(torch.randn(orr.shape, generator=torch.Generator().manual_seed(5)))
+        assert rel_err(o1.numpy(), orr.detach().numpy()) < 1e-4
+        assert rel_err(gx1.numpy(), xr.grad.numpy()) < 3e-4 and rel_err(gw1.numpy(), w1r.grad.numpy()) < 3e-4
+
+
+def test_fused_backward_sums_need_the_callers_exclusive_flag():
+    """Without exclusive=True the producer's sums are never taken from the consumer, whatever autograd does with the
+    gradient: a second consumer made of plain torch ops (a view of the tensor) accumulates into the same buffer."""
+    from pix2pixhdaudiosr_amd import _ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 48, 40, generator=g).cuda().requires_grad_(True)
+    w1 = (torch.randn(24, 16, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True)
+    w2 = (torch.randn(32, 24, 3, 3, generator=g) * 0.05).cuda().requires_grad_(True)
+    specP = _ops.ConvSpec(16, 24, 3, 1, 1, 0, False, 0, True, _ops.ACT_RELU)
+    specL = _ops.ConvSpec(24, 32, 3, 2, 1, 0, False, 0, True, _ops.ACT_RELU)
+    h = _ops.conv_block(_ops.ToPhysical.apply(torch.float32, x), w1, None, specP)
+    o = _ops.conv_block(h, w2, None, specL)
+    n0 = _ops._BSUM_CALLS[0]
+    (o.float().sum() + (h[..., :24].float() ** 2).sum()).backward()
+    assert _ops._BSUM_CALLS[0] == n0
+    xr, w1r, w2r = (t.detach().cpu().requires_grad_(True) for t in (x, w1, w2))
+    hr = F.relu(F.instance_norm(F.conv2d(xr, w1r, padding=1), eps=1e-5))
+    orr = F.relu(F.instance_norm(F.conv2d(hr, w2r, stride=2, padding=1), eps=1e-5))
+    (orr.sum() + (hr ** 2).sum()).backward()
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.numpy()) < 3e-4 and rel_err(w1.grad.cpu().numpy(), w1r.grad.numpy()) < 3e-4
