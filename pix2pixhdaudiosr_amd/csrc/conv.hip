@@ -1507,7 +1507,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
   // where 128-wide tiles would gather the A operand once more and pad the last tile
-  if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && k <= 384 &&
+  if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && (k <= 384 || d.bs_out != nullptr) &&
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)
