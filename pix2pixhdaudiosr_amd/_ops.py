@@ -469,8 +469,8 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.arena_gen = arena_generation(x.device) if spec.norm else 0
         ctx._p2phd_consumers = 0                                   # forward calls that read `out` (see _note_consumer)
         ctx._bs = None                                             # (bstats, data_ptr, version) left by the consumer's dgrad
-        ctx.src = src if (src is not None and hasattr(src, "_p2phd_consumers") and getattr(src, "spec", None) is not None
-                          and src.spec.norm) else None
+        ctx._parked = None                                         # gradient of `out` parked by a loss (LossFn, park=True)
+        ctx.src = src if (src is not None and hasattr(src, "_p2phd_consumers") and getattr(src, "spec", None) is not None) else None
         return out
 
     @staticmethod
@@ -482,6 +482,12 @@ class ConvBlockFn(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
+        parked, ctx._parked = ctx._parked, None
+        if parked is not None:
+            # a loss parked its gradient of this block's output for the consumer's input-gradient kernel to add, and that
+            # kernel did not take it (it ran first, or does not exist in this backward pass): add it here
+            g = g + parked.to(g.dtype)
+            ctx._bs = None
         N, Ho, Wo, Cp_out = y.shape
         need_w = ((ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
                   and id(weight) not in _BWD_SKIP_WGRAD_IDS)
@@ -545,7 +551,11 @@ class ConvBlockFn(torch.autograd.Function):
             if ctx.link is not None and ctx.link.role_of(ctx) == "a":
                 addend = ctx.link.take()
             src = ctx.src
-            fuse = (src is not None and src._p2phd_consumers == 1 and _bsum_enabled() and src.y is not None
+            if src is not None and src._parked is not None and src._p2phd_consumers == 1:
+                # feature-matching gradient of x parked by the loss: summed inside this kernel instead of by autograd
+                pk, src._parked = src._parked, None
+                addend = pk if addend is None else addend + pk
+            fuse = (src is not None and src.spec.norm and src._p2phd_consumers == 1 and _bsum_enabled() and src.y is not None
                     and src.y.shape == x.shape and src.y.dtype == x.dtype and src.spec.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
                     and L.p2phd_instnorm_act_bwd_two_pass(d.dtype, x.shape[0], x.shape[1] * x.shape[2], spec.cin)
                     and L.p2phd_conv_dgrad_bsum_ok(C.byref(d)))
@@ -635,8 +645,11 @@ class LossFn(torch.autograd.Function):
     """kind 0: mean((a-target)^2) ; kind 1: mean(|a-b|) * coeff.  Returns a 0-dim f32 device tensor."""
 
     @staticmethod
-    def forward(ctx, a, b, kind, target, coeff, channels):
-        _note_consumer(a)
+    def forward(ctx, a, b, kind, target, coeff, channels, park=False):
+        gf = getattr(a, "grad_fn", None)
+        ctx.park_src = gf if (park and gf is not None and hasattr(gf, "_p2phd_consumers") and hasattr(gf, "_parked")) else None
+        if ctx.park_src is None:
+            _note_consumer(a)
         a = phys(a, "loss input")
         P = a.numel() // a.shape[-1]
         out = zeros((), a.device)
@@ -657,12 +670,21 @@ class LossFn(torch.autograd.Function):
         if _BWD_TRACE[0] is not None:
             _BWD_TRACE[0].append((("loss", kind, tuple(a.shape), coeff), g.detach().clone(), da.detach().clone(),
                                   None if b is None else b.detach().clone()))
-        return da, None, None, None, None, None
+        if ctx.park_src is not None:
+            # hand the gradient to the block that produced `a`: its exclusive consumer adds it inside its input-gradient
+            # kernel (or the block itself does, if that kernel is not part of this backward pass); autograd gets nothing
+            src = ctx.park_src
+            src._parked = da if src._parked is None else src._parked + da
+            return None, None, None, None, None, None, None
+        return da, None, None, None, None, None, None
 
 
 def mse_const_loss(a_phys, channels, target):
     return LossFn.apply(a_phys, None, 0, target, 1.0, channels)
 
 
-def l1_loss(a_phys, b_phys, channels, coeff=1.0):
-    return LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels)
+def l1_loss(a_phys, b_phys, channels, coeff=1.0, park=False):
+    """`park`: a_phys is the output of a conv block whose only other consumer is the next conv block of an exclusive chain
+    (networks._run): the loss gradient is parked on the producer and added inside that consumer's input-gradient kernel
+    instead of by an autograd accumulation launch (and the InstanceNorm-backward sums can be fused there, see _bsum_enabled)."""
+    return LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels, park)

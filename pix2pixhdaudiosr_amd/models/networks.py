@@ -205,13 +205,13 @@ def enable_fp8(net, min_channels=256):
     return n
 
 
-def _run(steps, x, residual_last=None, cuts=None, cut_after=()):
+def _run(steps, x, residual_last=None, cuts=None, cut_after=(), first_exclusive=False):
     """Run fused steps in order.  `cuts` (a list) collects the output of every step whose index is in `cut_after`: the
     points where the staged backward of the data-parallel step hands over (Pix2PixHDModel._phase_a)."""
     for j, s in enumerate(steps):
         # from the second step on, the input is the previous step's output and is consumed here only (a cut tensor is an
         # endpoint of torch.autograd.grad, not a consumer): the step may fuse the producer's backward sums (_ops)
-        x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0)
+        x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0 or first_exclusive)
         if cuts is not None and j in cut_after:
             cuts.append(x)
     return x
@@ -468,14 +468,16 @@ class MultiscaleDiscriminator(_HipNet):
         flat = self._steps('layer%d' % d)
         return [[s] for s in flat]
 
-    def forward_physical(self, x):
-        """list[num_D] of list of (physical tensor, channels); all stages if getIntermFeat else the last only."""
+    def forward_physical(self, x, exclusive=False):
+        """list[num_D] of list of (physical tensor, channels); all stages if getIntermFeat else the last only.
+        `exclusive`: the caller promises that the only gradient an intermediate feature receives besides its next stage's
+        comes from `_ops.l1_loss(..., park=True)` (Pix2PixHDModel._losses): the stages then form an exclusive chain."""
         result, cur = [], x
         for i in range(self.num_D):
             stages = self._scale_steps(self.num_D - 1 - i)          # reference networks.py:325
             feats, h = [], cur
             for j, st in enumerate(stages):
-                h = _run(st, h)
+                h = _run(st, h, first_exclusive=exclusive and j > 0)
                 feats.append((h, self.channels[j]))
             result.append(feats if self.getIntermFeat else [feats[-1]])
             if i != self.num_D - 1:

@@ -272,7 +272,9 @@ class Pix2PixHDModel(BaseModel):
     # ------------------------------------------------------------------------------------------
     def _D(self, lr_spectro, other):
         """netD on cat(lr, other) -> list[num_D] of list of (physical tensor, channels)."""
-        return self.netD.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro, other))
+        # exclusive: intermediate features leave this module only through _losses, whose feature-matching terms park
+        # their gradient (l1_loss(..., park=True)) and whose real-side features are detached
+        return self.netD.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro, other), exclusive=True)
 
     @staticmethod
     def _gan(pred, target):
@@ -326,7 +328,7 @@ class Pix2PixHDModel(BaseModel):
             for i in range(self.opt.num_D):
                 for j in range(len(pred_fake[i]) - 1):
                     (a, c), (b, _) = pred_fake[i][j], pred_real[i][j]
-                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, D_weights * feat_weights * self.opt.lambda_feat)
+                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, D_weights * feat_weights * self.opt.lambda_feat, park=True)
 
         # TDAC frame-matching loss (pix2pixHD_model.py:408-415): the second half of frame t and the first half of frame
         # t+1, each under its window half, must coincide
