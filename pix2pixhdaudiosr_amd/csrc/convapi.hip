@@ -503,7 +503,7 @@ namespace {
 // on a tile shape that has the fused store loop (gconv 256x256 does not: see launch_gconv_t)
 bool dgrad_bsum_plans(const p2phd_conv_desc* c, std::vector<Plan>& plans) {
   if (check_desc(c) != P2PHD_OK || c->N == 0) return false;
-  if (c->pad_mode == 1 || fold_mode(c) == FOLD_OUT || c7_out_dgrad_ok(c)) return false;
+  if (c->pad_mode == 1 || c7_out_dgrad_ok(c)) return false;     // (the output W-fold is fine: its launch writes dx directly too)
   WMap m;
   make_plans(c, 1, plans, &m);
   return plans.size() == 1;
@@ -518,7 +518,13 @@ extern "C" int p2phd_conv_dgrad_bsum_ok(const p2phd_conv_desc* c) {
 extern "C" size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c) {
   std::vector<Plan> plans;
   if (!dgrad_bsum_plans(c, plans)) return 0;
-  return align256(bsum_table_floats(plans[0].d) * sizeof(float));
+  size_t n = align256(bsum_table_floats(plans[0].d) * sizeof(float));
+  if (fold_mode(c) == FOLD_OUT) {                                // + the W-folded dy image of the 1-channel head
+    int Ho, Wo;
+    out_size(c, &Ho, &Wo);
+    n += folded_dy_bytes(c, Ho, Wo);
+  }
+  return n;
 }
 
 extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, const void* wp, const void* addend, void* dx,
@@ -537,8 +543,16 @@ extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, c
   p.d.bs_eps = eps;
   p.d.bs_slope = prev_act == P2PHD_ACT_RELU ? 0.f : (prev_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
   const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
+  const void* src = dy;
+  if (fold_mode(c) == FOLD_OUT) {
+    int Ho, Wo;
+    out_size(c, &Ho, &Wo);
+    void* dye = static_cast<char*>(workspace) + align256(bsum_table_floats(p.d) * sizeof(float));
+    if (int rc = launch_expand_dy(c->dtype, dy, dye, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
+    src = dye;
+  }
   int tile_rows = 0;
-  if (int rc = launch_gconv(p.d, c->dtype, dy, w, nullptr, addend, dx, nullptr, st, &tile_rows)) return rc;
+  if (int rc = launch_gconv(p.d, c->dtype, src, w, nullptr, addend, dx, nullptr, st, &tile_rows)) return rc;
   const int n_extent = p.d.n_extent ? p.d.n_extent : p.d.Cp_out;
   return launch_bsum_merge(p.d.bs_out, bstats, c->N, (long)p.d.Hg * p.d.Wg, tile_rows, n_extent, p.d.cls_cp, cpitch(c->C), c->C, st);
 }

@@ -374,7 +374,7 @@ def test_trunk_layer_at_baseline_size():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
-@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide"])
+@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide", "head_to1"])
 def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, tol, monkeypatch):
     """p2phd_conv_dgrad_bsum: the input-gradient kernel of the consumer leaves the (sum g', sum g' yhat) of the producer's
     InstanceNorm backward, which then runs its apply pass only.  Same gradients as the two-pass form (P2PHD_BSUM=0) up to
@@ -385,13 +385,14 @@ def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, 
     if consumer == "s1_256wide":
         C1 = 256
     c2 = {"s2_conv": (C1, 32, 3, 2, 1, 0, False, 0), "s1_conv": (C1, 40, 3, 1, 1, 0, False, 0),
-          "conv_transpose": (C1, 16, 3, 2, 1, 0, True, 1), "s1_256wide": (C1, 256, 3, 1, 1, 0, False, 0)}[consumer]
+          "conv_transpose": (C1, 16, 3, 2, 1, 0, True, 1), "s1_256wide": (C1, 256, 3, 1, 1, 0, False, 0),
+          "head_to1": (C1, 1, 3, 1, 1, 0, False, 0)}[consumer]      # 1-channel head: output W-fold in front of the launch
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, C0, H, W, generator=g)
     w1 = torch.randn(C1, C0, 3, 3, generator=g) * 0.1
     w2 = torch.randn((c2[0], c2[1], 3, 3) if c2[6] else (c2[1], c2[0], 3, 3), generator=g) * 0.05
     specP = _ops.ConvSpec(C0, C1, 3, 1, 1, 0, False, 0, True, _ops.ACT_RELU)
-    specL = _ops.ConvSpec(*c2, True, _ops.ACT_RELU)
+    specL = _ops.ConvSpec(*c2, consumer != "head_to1", _ops.ACT_RELU if consumer != "head_to1" else _ops.ACT_NONE)
 
     def run(flag):
         monkeypatch.setenv("P2PHD_BSUM", flag)
@@ -419,7 +420,8 @@ def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, 
             orr = F.conv_transpose2d(hr, w2r, stride=2, padding=1, output_padding=1)
         else:
             orr = F.conv2d(hr, w2r, stride=c2[3], padding=1)
-        orr = F.relu(F.instance_norm(orr, eps=1e-5))
+        if consumer != "head_to1":
+            orr = F.relu(F.instance_norm(orr, eps=1e-5))
         orr.backward(torch.randn(orr.shape, generator=torch.Generator().manual_seed(5)))
         assert rel_err(o1.numpy(), orr.detach().numpy()) < 1e-4
         assert rel_err(gx1.numpy(), xr.grad.numpy()) < 3e-4 and rel_err(gw1.numpy(), w1r.grad.numpy()) < 3e-4
