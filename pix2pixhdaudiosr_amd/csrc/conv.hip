@@ -1511,16 +1511,6 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)
-    if (huge && force == 0 && (fits3 || fits2) && bn == 128) {
-      // rounds x tile width: a 256-wide grid of 257..300 workgroups runs two rounds for barely more than one round of
-      // work (the discriminator's 256-channel input gradient: 269 tiles); 128-wide tiles then cost less in total
-      const long wg256 = mt256 * ((k + 255) / 256), wg128 = mt256 * ((k + 127) / 128);
-      const double c256 = std::ceil(wg256 / 256.0) * 256.0, c128 = std::ceil(wg128 / 256.0) * 128.0 / 0.85;
-      if (c128 < c256) {
-        if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
-        return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);   // 16-tap gather table
-      }
-    }
     if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   if (big && bn == 128) {

@@ -19,7 +19,7 @@ def t_us(fn, it=5):
         ts.append(e0.elapsed_time(e1) / it * 1e3)
     return sorted(ts)[2]
 
-def case(name, cin, cout, k, stride, pad, transposed, opad, H, W):
+def case(name, cin, cout, k, stride, pad, transposed, opad, H, W, act=None):
     """consumer conv reads the producer plane [B, H, W, cin]"""
     spec = _ops.ConvSpec(cin, cout, k, stride, pad, 0, transposed, opad, True, _ops.ACT_RELU)
     d = spec.desc(B, H, W, dt)
@@ -35,7 +35,7 @@ def case(name, cin, cout, k, stride, pad, transposed, opad, H, W):
     ws = torch.empty(max(L.p2phd_conv_dgrad_workspace_bytes(C.byref(d)), L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
     P, S = _ops.ptr, _ops.stream_ptr
     dg = lambda: _ops.check(L.p2phd_conv_dgrad(C.byref(d), P(dy), P(wp), None, P(gx), P(ws), S()))
-    two = lambda: _ops.check(L.p2phd_instnorm_act_bwd(d.dtype, P(gx), P(yprev), P(stats), P(bst), P(dprev), None, B, H * W, cin, 1e-5, _ops.ACT_RELU, S()))
+    two = lambda: _ops.check(L.p2phd_instnorm_act_bwd(d.dtype, P(gx), P(yprev), P(stats), P(bst), P(dprev), None, B, H * W, cin, 1e-5, (act or _ops.ACT_RELU), S()))
     dgb = lambda: _ops.check(L.p2phd_conv_dgrad_bsum(C.byref(d), P(dy), P(wp), None, P(gx), P(yprev), P(stats), _ops.ACT_RELU, 1e-5, P(bst), P(ws), S()))
     app = lambda: _ops.check(L.p2phd_instnorm_act_bwd_apply(d.dtype, P(gx), P(yprev), P(stats), P(bst), P(dprev), None, 0, B, H * W, cin, 1e-5, _ops.ACT_RELU, S()))
     assert L.p2phd_conv_dgrad_bsum_ok(C.byref(d))
@@ -49,3 +49,8 @@ case("down3-out 64x32x384 <- down4", 384, 768, 3, 2, 1, False, 0, 64, 32)
 case("up1-out 64x32x384 <- up2 (convT)", 384, 192, 3, 2, 1, True, 1, 64, 32)
 case("up2-out 128x64x192 <- up3 (convT)", 192, 96, 3, 2, 1, True, 1, 128, 64)
 case("up3-out 256x128x96 <- up4 (convT)", 96, 48, 3, 2, 1, True, 1, 256, 128)
+
+print("discriminator (LeakyReLU planes):")
+case("D 64->128 out 129x65x128 <- 128->256", 128, 256, 4, 2, 2, False, 0, 129, 65)
+case("D 128->256 out 65x33x256 <- 256->512", 256, 512, 4, 1, 2, False, 0, 65, 33)
+case("D 256->512 out 66x34x512 <- 512->1", 512, 1, 4, 1, 2, False, 0, 66, 34)
