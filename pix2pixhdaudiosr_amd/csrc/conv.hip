@@ -151,6 +151,15 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         int hi = ho * sh + dh0 + ta * dhs;
         int wi = wo * sw + dw0 + tb * dws;
         if (pad_mode == 1) { hi = reflect_idx(hi, Hin); wi = reflect_idx(wi, Win); }
+        if (pad_mode == 2) {
+          // adjoint of ReflectionPad2d(1) in front of a 3x3 conv, on the EXACT grid: the gathered tensor is dy extended
+          // by two virtual rows / columns holding dy[0] + dy[2] and dy[H-3] + dy[H-1] (reflect_expand_kernel); output
+          // row 1 reads the first through its tap -1 (where plain zero padding reads dy[2]), row H-2 the second
+          // through its tap +1 (instead of dy[H-3]); everything else is the zero-padded transposed conv
+          const int Hr = Hin - 2, Wr = Win - 2;
+          if (ho == 1 && hi == 2) hi = Hr; else if (ho == Hr - 2 && hi == Hr - 3) hi = Hr + 1; else if (hi >= Hr) hi = -1;
+          if (wo == 1 && wi == 2) wi = Wr; else if (wo == Wr - 2 && wi == Wr - 3) wi = Wr + 1; else if (wi >= Wr) wi = -1;
+        }
         if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (nn * Hin + hi) * Win + wi;
       }
       tab[t * BM + r] = off;
@@ -1342,6 +1351,46 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(GDesc d, p2phd::WMap m, c
   }
 }
 
+// E[n, r', c', :] for the pad_mode 2 gather (see gconv_kernel): rows r' < H are dy's, r' = H holds dy[0] + dy[2],
+// r' = H + 1 holds dy[H-3] + dy[H-1]; the same along W (corners: sums of sums).  H, W >= 3.
+template <typename T>
+__global__ void reflect_expand_kernel(const T* __restrict__ dy, T* __restrict__ e_out, int N, int H, int W, int Cp) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const int He = H + 2, We = W + 2;
+  const long total = (long)N * He * We * cpr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int pc = (int)(e % cpr);
+    long r = e / cpr;
+    const int j = (int)(r % We); r /= We;
+    const int i = (int)(r % He);
+    const int n = (int)(r / He);
+    int hs[2], ws[2], nh = 1, nw = 1;
+    hs[0] = i; ws[0] = j;
+    if (i == H) { hs[0] = 0; hs[nh++] = 2; } else if (i == H + 1) { hs[0] = H - 3; hs[nh++] = H - 1; }
+    if (j == W) { ws[0] = 0; ws[nw++] = 2; } else if (j == W + 1) { ws[0] = W - 3; ws[nw++] = W - 1; }
+    uint4 ov;
+    if (nh == 1 && nw == 1) {
+      ov = *reinterpret_cast<const uint4*>(dy + (((size_t)n * H + hs[0]) * W + ws[0]) * Cp + pc * EPP);
+    } else {
+      float acc[EPP];
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
+      for (int a = 0; a < nh; ++a)
+        for (int b = 0; b < nw; ++b) {
+          const uint4 v = *reinterpret_cast<const uint4*>(dy + (((size_t)n * H + hs[a]) * W + ws[b]) * Cp + pc * EPP);
+          const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+          for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+        }
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) oo[k] = from_f<T>(acc[k]);
+    }
+    *reinterpret_cast<uint4*>(e_out + (size_t)e * EPP) = ov;
+  }
+}
+
 // reflect-pad adjoint: dx[n,i,j,:] = sum over padded positions that mirror onto (i,j) of dxp (+ addend)
 template <typename T>
 __global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restrict__ addend, T* __restrict__ dx,
@@ -1356,12 +1405,12 @@ __global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restri
     const int j = (int)(r % W); r /= W;
     const int i = (int)(r % H);
     const int n = (int)(r / H);
-    int hs[2], ws[2], nh = 1, nw = 1;
+    int hs[3], ws[3], nh = 1, nw = 1;                            // a row within P of BOTH borders (H <= 2 P + 1) has two mirrors
     hs[0] = i + P; ws[0] = j + P;
     if (i >= 1 && i <= P) hs[nh++] = P - i;
-    else if (i >= H - 1 - P && i <= H - 2) hs[nh++] = 2 * (H - 1) - i + P;
+    if (i >= H - 1 - P && i <= H - 2) hs[nh++] = 2 * (H - 1) - i + P;
     if (j >= 1 && j <= P) ws[nw++] = P - j;
-    else if (j >= W - 1 - P && j <= W - 2) ws[nw++] = 2 * (W - 1) - j + P;
+    if (j >= W - 1 - P && j <= W - 2) ws[nw++] = 2 * (W - 1) - j + P;
     float acc[EPP];
 #pragma unroll
     for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
@@ -1729,6 +1778,17 @@ int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx
   else
     hipLaunchKernelGGL(reflect_fold_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dxp, (const float*)addend, (float*)dx, N, H, W, Cp, P);
   return check_launch("reflect_fold");
+}
+
+int launch_reflect_expand(int dtype, const void* dy, void* e_out, int N, int H, int W, int Cp, hipStream_t st) {
+  const int epp = dtype == P2PHD_BF16 ? 8 : 4;
+  const long total = (long)N * (H + 2) * (W + 2) * (Cp / epp);
+  const int blocks = (int)std::min<long>((total + 255) / 256, 8192);
+  if (dtype == P2PHD_BF16)
+    hipLaunchKernelGGL(reflect_expand_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)e_out, N, H, W, Cp);
+  else
+    hipLaunchKernelGGL(reflect_expand_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)dy, (float*)e_out, N, H, W, Cp);
+  return check_launch("reflect_expand");
 }
 
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st) {

@@ -456,6 +456,10 @@ extern "C" size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c) {
   out_size(c, &Ho, &Wo);
   size_t n = padded_dx_bytes(c);
   if (fold_mode(c) == FOLD_OUT) n += folded_dy_bytes(c, Ho, Wo);
+  // the exact-grid form of a reflect-padded 3x3 input gradient keeps dy + its pair-sum rows / columns here instead:
+  // [N][H + 2][W + 2][Cp(K)] -- K channels, where the padded-grid gradient has C
+  if (c->pad_mode == 1 && c->R == 3 && c->S == 3 && c->pad == 1 && c->stride == 1 && !c->transposed)
+    n = std::max(n, align256((size_t)c->N * (c->H + 2) * (c->W + 2) * cpitch(c->K) * elem_size(c->dtype)));
   return n;
 }
 
@@ -481,6 +485,20 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
     return c7_out_dgrad(c, dy, frag, master, dx, st);
   }
   P2PHD_REQUIRE(!(reflect || kfold) || workspace, "conv_dgrad: this layer needs p2phd_conv_dgrad_workspace_bytes of scratch");
+  if (reflect && !kfold && !c->transposed && c->R == 3 && c->S == 3 && c->pad == 1 && c->stride == 1 && c->H >= 4 && c->W >= 4 &&
+      !g_opt_reflect_generic) {
+    // 3x3 behind ReflectionPad2d(1) (the residual trunk, networks.py:231-252): the adjoint of the reflection is moved
+    // in front of the GEMM -- dy gets two virtual rows / columns holding the pair sums the mirrored taps need -- and the
+    // input gradient runs on the exact H x W grid (pad_mode 2 gather), straight into dx with the skip gradient as
+    // addend: no padded-grid tensor (+19.5 % rows at 32 x 16) and no fold pass
+    std::vector<Plan> ex;
+    transposed_plans(c->N, c->H + 2, c->W + 2, c->K, c->H, c->W, c->C, c->R, c->S, 1, 1, ex);
+    P2PHD_REQUIRE(ex.size() == 1 && ex[0].d.KK == plans[0].d.KK && ex[0].rows_pad == plans[0].rows_pad, "conv_dgrad: plan mismatch");
+    ex[0].d.pad_mode = 2;
+    if (int rc = launch_reflect_expand(c->dtype, dy, workspace, c->N, c->H, c->W, cpitch(c->K), st)) return rc;
+    return launch_gconv(ex[0].d, c->dtype, workspace, static_cast<const char*>(wp) + plans[0].w_off * elem_size(c->dtype), nullptr,
+                        addend, dx, nullptr, st);
+  }
   char* ws = static_cast<char*>(workspace);
   void* dxp = ws;                                   // padded-grid gradient (reflect only)
   const void* src = dy;

@@ -55,6 +55,7 @@ int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, in
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
 extern int g_opt_c7_generic;
+extern int g_opt_reflect_generic;   // 1: reflect-padded 3x3 input gradients on the padded grid + fold (the general form)
 extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 
 // c7.hip: dedicated bf16 kernels of the generator's 7x7 end layers (full tiles of 8 x 128 pixels only)
@@ -105,6 +106,7 @@ int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int
 int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int rows_pad, int K, int C, int R, int S, int pad,
                        long s_k, long s_c, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
+int launch_reflect_expand(int dtype, const void* dy, void* e_out, int N, int H, int W, int Cp, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st);

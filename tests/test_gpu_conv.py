@@ -447,3 +447,39 @@ def test_fused_backward_sums_need_the_callers_exclusive_flag():
     orr = F.relu(F.instance_norm(F.conv2d(hr, w2r, stride=2, padding=1), eps=1e-5))
     (orr.sum() + (hr ** 2).sum()).backward()
     assert rel_err(x.grad.cpu().numpy(), xr.grad.numpy()) < 3e-4 and rel_err(w1.grad.cpu().numpy(), w1r.grad.numpy()) < 3e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 4, 4), (2, 24, 16, 5, 7), (3, 40, 72, 32, 16), (1, 8, 8, 3, 9)])
+def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(shape, dtype, tol):
+    """Input gradient of Conv3x3 behind ReflectionPad2d(1) (the residual trunk): the exact-grid form (dy extended by the
+    pair-sum rows / columns the mirrored taps read, pad_mode 2 gather, no fold pass) against the general padded-grid + fold
+    form (`reflect_generic`), with a skip-gradient addend, incl. planes where rows 1 and H-2 coincide or neighbour (H = 3, 4)
+    -- H = 3 takes the general form by itself -- and against the fp32 oracle."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _lib.lib()
+    N, cin, cout, H, W = shape
+    g = torch.Generator().manual_seed(H * 100 + W)
+    dy = torch.randn(N, cout, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.1
+    add = torch.randn(N, cin, H, W, generator=g)
+    spec = _ops.ConvSpec(cin, cout, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, dtype)
+    dyp = _ops.to_physical(dy.cuda(), dtype); addp = _ops.to_physical(add.cuda(), dtype)
+    wp = spec.packed(w.cuda(), 1, d)
+    ws = torch.empty(max(L.p2phd_conv_dgrad_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
+    outs = []
+    for generic in (0, 1):
+        _lib.check(L.p2phd_set_option(b"reflect_generic", generic))
+        try:
+            gx = torch.empty_like(addp)
+            _ops.check(L.p2phd_conv_dgrad(C.byref(d), _ops.ptr(dyp), _ops.ptr(wp), _ops.ptr(addp), _ops.ptr(gx), _ops.ptr(ws), _ops.stream_ptr()))
+            outs.append(_ops.from_physical(gx, cin).cpu())
+        finally:
+            _lib.check(L.p2phd_set_option(b"reflect_generic", 0))
+    assert rel_err(outs[0].numpy(), outs[1].numpy()) < tol
+    if dtype == torch.float32:
+        x = torch.zeros(N, cin, H, W, requires_grad=True)
+        F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w).backward(dy)
+        assert rel_err(outs[0].numpy(), (x.grad + add).numpy()) < 1e-5
