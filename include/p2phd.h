@@ -176,6 +176,12 @@ size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, const void* packed, const void* addend, void* dx,
                           const void* prev_y, const float* prev_stats, int prev_act, float eps, float* bstats,
                           void* workspace, void* stream);
+/* The same store loop for a producer WITHOUT InstanceNorm (Conv + ReLU / LeakyReLU(0.2)): x_act is that block's output --
+ * the tensor this conv read -- and dx leaves multiplied by act'(x_act), i.e. as the gradient of the producer's
+ * pre-activation; its activation-backward pass (p2phd_act_bwd / p2phd_act_bwd_db) is then not needed.  Same availability
+ * and workspace as p2phd_conv_dgrad_bsum. */
+int p2phd_conv_dgrad_act(const p2phd_conv_desc* c, const void* dy, const void* packed, const void* addend, void* dx,
+                         const void* x_act, int prev_act, void* workspace, void* stream);
 
 /* dw (master layout, f32, overwritten) and db (f32 [K], overwritten, may be NULL) from x and dy. */
 size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c);

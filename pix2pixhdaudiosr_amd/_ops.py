@@ -470,6 +470,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx._p2phd_consumers = 0                                   # forward calls that read `out` (see _note_consumer)
         ctx._bs = None                                             # (bstats, data_ptr, version) left by the consumer's dgrad
         ctx._parked = None                                         # gradient of `out` parked by a loss (LossFn, park=True)
+        ctx._dy_done = None                                        # (data_ptr, version) of a gradient that already carries act' 
         ctx.src = src if (src is not None and hasattr(src, "_p2phd_consumers") and getattr(src, "spec", None) is not None) else None
         return out
 
@@ -483,7 +484,9 @@ class ConvBlockFn(torch.autograd.Function):
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
         parked, ctx._parked = ctx._parked, None
+        dy_done, ctx._dy_done = ctx._dy_done, None                 # (consumed once: a marker must not outlive its backward pass)
         if parked is not None:
+            dy_done = None
             # a loss parked its gradient of this block's output for the consumer's input-gradient kernel to add, and that
             # kernel did not take it (it ran first, or does not exist in this backward pass): add it here
             g = g + parked.to(g.dtype)
@@ -513,6 +516,9 @@ class ConvBlockFn(torch.autograd.Function):
                 check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
                           stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
+        elif spec.act != ACT_NONE and dy_done is not None and dy_done == (g.data_ptr(), g._version) and g.shape == y.shape:
+            dy = g                                                 # the consumer's input-gradient kernel applied act' already
+            _BSUM_CALLS[0] += 1
         elif spec.act != ACT_NONE:
             dy = empty_like(y)
             if gb is not None:                                     # bias gradient rides on the activation-backward pass
@@ -566,6 +572,14 @@ class ConvBlockFn(torch.autograd.Function):
                 check(L.p2phd_conv_dgrad_bsum(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src.y), ptr(src.stats),
                                               src.spec.act, IN_EPS, ptr(bst), ptr(wsf), stream_ptr()), "conv_dgrad_bsum")
                 src._bs = (bst, gx.data_ptr(), gx._version)
+            elif (src is not None and not src.spec.norm and src.spec.act in (ACT_RELU, ACT_LRELU) and src._p2phd_consumers == 1
+                  and _bsum_enabled() and src.y is not None and src.y.shape == x.shape and src.y.dtype == x.dtype
+                  and L.p2phd_conv_dgrad_bsum_ok(C.byref(d))):
+                # producer = Conv + (Leaky)ReLU without normalisation: its activation derivative is applied to gx here
+                wsf = workspace(max(L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 256), y.device)
+                check(L.p2phd_conv_dgrad_act(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src.y), src.spec.act, ptr(wsf),
+                                             stream_ptr()), "conv_dgrad_act")
+                src._dy_done = (gx.data_ptr(), gx._version)
             else:
                 check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
         if _BWD_TRACE[0] is not None:

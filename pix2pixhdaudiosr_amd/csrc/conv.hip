@@ -514,8 +514,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   constexpr int CPR = BN / EPPO;                             // 16-byte pieces per C-tile row
   const int Hout = d.Hout, Wout = d.Wout, ohm = d.oh_mul, oho = d.oh_off, owm = d.ow_mul, owo = d.ow_off;
   if constexpr (MR * NR <= 6 && sizeof(T) != 1) {
-    if (d.bs_out != nullptr) {
-      // Store loop with the consumer's InstanceNorm-backward sums riding on it (GDesc::bs_out).  A thread keeps ONE
+    if (d.bs_out != nullptr || d.as_x != nullptr) {
+      // Store loop with the consumer's InstanceNorm-backward sums riding on it (GDesc::bs_out) -- or, for a producer
+      // without normalisation, just its activation derivative applied to the stored gradient (GDesc::as_x).  A thread keeps ONE
       // piece column (8 / 4 channels) for all its rows, so the channel constants are loaded once and the sums stay in
       // registers; they are folded over the threads of a column through LDS in a fixed order (no atomics) and leave as
       // this tile's row of the partial table.
@@ -529,12 +530,13 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
       for (int e = 0; e < EPPO; ++e) {
         a1[e] = a2[e] = 0.f;
-        const bool ch_ok = col_ok && kch + e < Kout;
+        const bool ch_ok = col_ok && kch + e < Kout && d.bs_out != nullptr;
         const float2 ms = ch_ok ? *reinterpret_cast<const float2*>(d.bs_stats + 2 * ((size_t)n * Cp_out + kch + e)) : make_float2(0.f, 0.f);
         mean_b[e] = ms.x;
         rstd_b[e] = ch_ok ? rsqrtf(fmaxf(ms.y * d.bs_inv_hw, 0.f) + d.bs_eps) : 0.f;
       }
-      const TO* bsy = reinterpret_cast<const TO*>(d.bs_y);
+      const bool act_only = d.bs_out == nullptr;
+      const TO* bsy = reinterpret_cast<const TO*>(act_only ? d.as_x : d.bs_y);
       const float slope_b = d.bs_slope;
       if (col_ok) {
         // U rows at a time: their pre-normalisation pieces (and addends) are all requested before the first one is used --
@@ -570,9 +572,16 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
               for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) + to_f(aa[e]));
             }
+            const TO* yy = reinterpret_cast<const TO*>(&yv[u]);
+            if (act_only) {
+              TO* vv = reinterpret_cast<TO*>(&v);
+#pragma unroll
+              for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) * (to_f(yy[e]) > 0.f ? 1.f : slope_b));
+              *reinterpret_cast<uint4*>(out + opx[u] * Cp_out + kch) = v;
+              continue;
+            }
             *reinterpret_cast<uint4*>(out + opx[u] * Cp_out + kch) = v;
             const TO* gg = reinterpret_cast<const TO*>(&v);      // the ROUNDED gradient: what the apply pass will read
-            const TO* yy = reinterpret_cast<const TO*>(&yv[u]);
 #pragma unroll
             for (int e = 0; e < EPPO; ++e) {
               const float yh = (to_f(yy[e]) - mean_b[e]) * rstd_b[e];
@@ -582,6 +591,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
           }
         }
       }
+      if (act_only) return;
       __syncthreads();                                        // every thread is done with the C tile
       float* red = reinterpret_cast<float*>(ct);              // [NT][2 * EPPO]
 #pragma unroll
@@ -1531,7 +1541,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // grid still fills most of the chip.  256 x {128,64}: 3-slot ring when it fits beside the gather table, else 2-slot.
   const bool fits_huge = sizeof(T) == 2 && 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
   bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
-  if (d.bs_out != nullptr) huge = false;                     // (the 128-accumulator tile has no fused-sums store loop)
+  if (d.bs_out != nullptr || d.as_x != nullptr) huge = false;   // (the 128-accumulator tile has no fused store loop)
   const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
   const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(typename OutOf<T>::type) + 16) + tabb <= kLds;
   // short reductions (<= 4 K steps: the folded 2-channel layers, the 4-channel D input) are all prologue and epilogue:
@@ -1541,7 +1551,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   const int force = p2phd::g_opt_gconv_bm;
   if (force == 128) { big = false; huge = false; }
   if (force == 256) { big = fits3 || fits2; huge = false; }
-  if (force == 512) { huge = fits_huge && k > 128 && d.bs_out == nullptr; }
+  if (force == 512) { huge = fits_huge && k > 128 && d.bs_out == nullptr && d.as_x == nullptr; }
   // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)
   if (force == 192 && sizeof(T) <= 2 && k % 192 == 0 && 2 * 448 * kRowBytes + tabb <= kLds)
@@ -1556,7 +1566,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
   // where 128-wide tiles would gather the A operand once more and pad the last tile
-  if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && (k <= 384 || d.bs_out != nullptr) &&
+  if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && (k <= 384 || d.bs_out != nullptr || d.as_x != nullptr) &&
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)

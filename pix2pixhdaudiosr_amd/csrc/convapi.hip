@@ -575,6 +575,29 @@ extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, c
   return launch_bsum_merge(p.d.bs_out, bstats, c->N, (long)p.d.Hg * p.d.Wg, tile_rows, n_extent, p.d.cls_cp, cpitch(c->C), c->C, st);
 }
 
+extern "C" int p2phd_conv_dgrad_act(const p2phd_conv_desc* c, const void* dy, const void* wp, const void* addend, void* dx,
+                                    const void* x_act, int prev_act, void* workspace, void* stream) {
+  std::vector<Plan> plans;
+  P2PHD_REQUIRE(dgrad_bsum_plans(c, plans), "conv_dgrad_act: this layer's input gradient has no fused form (p2phd_conv_dgrad_bsum_ok)");
+  P2PHD_REQUIRE(dy && wp && dx && x_act, "conv_dgrad_act: null pointer");
+  P2PHD_REQUIRE(prev_act == P2PHD_ACT_RELU || prev_act == P2PHD_ACT_LRELU, "conv_dgrad_act: activation %d", prev_act);
+  hipStream_t st = (hipStream_t)stream;
+  Plan& p = plans[0];
+  p.d.as_x = x_act;
+  p.d.bs_slope = prev_act == P2PHD_ACT_RELU ? 0.f : 0.2f;
+  const char* w = static_cast<const char*>(wp) + p.w_off * elem_size(c->dtype);
+  const void* src = dy;
+  if (fold_mode(c) == FOLD_OUT) {
+    P2PHD_REQUIRE(workspace, "conv_dgrad_act: this layer needs p2phd_conv_dgrad_bsum_workspace_bytes of scratch");
+    int Ho, Wo;
+    out_size(c, &Ho, &Wo);
+    void* dye = static_cast<char*>(workspace) + align256(bsum_table_floats(p.d) * sizeof(float));
+    if (int rc = launch_expand_dy(c->dtype, dy, dye, c->N, Ho, Wo, Wo + c->S - 1, c->K, c->S, st)) return rc;
+    src = dye;
+  }
+  return launch_gconv(p.d, c->dtype, src, w, nullptr, addend, dx, nullptr, st);
+}
+
 namespace {
 // everything p2phd_conv_wgrad needs, derived once for both the workspace query and the call
 struct WgradSetup { Plan p; WMap m; int M; int Cp_r; int fold; size_t dwp_bytes; };

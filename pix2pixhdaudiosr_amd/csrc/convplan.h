@@ -29,6 +29,10 @@ struct GDesc {
   const float* bs_stats;
   float* bs_out;                              // nullptr = off
   float bs_inv_hw, bs_eps, bs_slope;          // 1 / pixels per plane, eps, negative slope of the activation (1 = none)
+  // Fused activation backward of a producer WITHOUT InstanceNorm (Conv + (Leaky)ReLU, e.g. the discriminator's first
+  // layer): as_x is that block's output (= the tensor this launch's conv read, same shape as the written gradient); the
+  // stored gradient is multiplied by act'(as_x) (1 above zero, bs_slope below) after the addend -- it leaves as dL/d(pre-act)
+  const void* as_x;
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:

@@ -483,3 +483,42 @@ def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(sha
         x = torch.zeros(N, cin, H, W, requires_grad=True)
         F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w).backward(dy)
         assert rel_err(outs[0].numpy(), (x.grad + add).numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypatch):
+    """Producer without InstanceNorm (Conv + LeakyReLU, the discriminator's first layer): the exclusive consumer's
+    input-gradient kernel multiplies dx by act'(x) (p2phd_conv_dgrad_act) and the producer skips its activation-backward
+    pass; bias and weight gradients of the producer come out the same, also with a parked loss gradient as addend."""
+    from pix2pixhdaudiosr_amd import _ops
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 66, 34, generator=g)
+    w1 = torch.randn(16, 4, 4, 4, generator=g) * 0.2; b1 = torch.randn(16, generator=g) * 0.1
+    w2 = torch.randn(32, 16, 4, 4, generator=g) * 0.05
+    ref_feat = torch.randn(2, 16, 34, 18, generator=g)
+    specP = _ops.ConvSpec(4, 16, 4, 2, 2, 0, False, 0, False, _ops.ACT_LRELU)
+    specL = _ops.ConvSpec(16, 32, 4, 2, 2, 0, False, 0, True, _ops.ACT_LRELU)
+
+    def run(flag):
+        monkeypatch.setenv("P2PHD_BSUM", flag)
+        xd = x.cuda().requires_grad_(True)
+        w1d, b1d, w2d = (t.cuda().requires_grad_(True) for t in (w1, b1, w2))
+        h = _ops.conv_block(_ops.ToPhysical.apply(dtype, xd), w1d, b1d, specP)
+        o = _ops.conv_block(h, w2d, None, specL, exclusive=True)
+        fm = _ops.l1_loss(h, _ops.to_physical(ref_feat.cuda(), dtype), 16, 3.0, park=True)     # second gradient source of h, parked
+        n0 = _ops._BSUM_CALLS[0]
+        (_ops.FromPhysical.apply(o, 32).sum() * 0.01 + fm).backward()
+        torch.cuda.synchronize()
+        return xd.grad.cpu(), w1d.grad.cpu(), b1d.grad.cpu(), w2d.grad.cpu(), _ops._BSUM_CALLS[0] - n0
+
+    a = run("1"); b = run("0")
+    assert a[4] == 1 and b[4] == 0
+    for u, v in zip(a[:4], b[:4]):
+        assert rel_err(u.numpy(), v.numpy()) < tol
+    if dtype == torch.float32:
+        xr, w1r, b1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, b1, w2))
+        hr = F.leaky_relu(F.conv2d(xr, w1r, b1r, stride=2, padding=2), 0.2)
+        orr = F.leaky_relu(F.instance_norm(F.conv2d(hr, w2r, stride=2, padding=2), eps=1e-5), 0.2)
+        (orr.sum() * 0.01 + 3.0 * (hr - ref_feat).abs().mean()).backward()
+        assert rel_err(a[0].numpy(), xr.grad.numpy()) < 3e-4 and rel_err(a[1].numpy(), w1r.grad.numpy()) < 3e-4
+        assert rel_err(a[2].numpy(), b1r.grad.numpy()) < 3e-4
