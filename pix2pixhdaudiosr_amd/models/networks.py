@@ -242,6 +242,22 @@ class _HipNet(nn.Module):
         return _ops.ToPhysical.apply(self._dtype(), x)
 
 
+def _centered_input(net, x):
+    """bf16 only: the generator's input minus its per-(sample, channel) mean.  The first layer of both generators is
+    ReflectionPad2d + Conv2d + InstanceNorm2d (networks.py:190, :268): a constant added to an input channel adds a constant
+    to every output channel (reflection padding keeps it constant up to the border), which the normalisation removes --
+    the result is unchanged in exact arithmetic.  In bf16 it is not: a [0, 1]-scaled dB spectrogram has |mean| / sigma of
+    10-25 per channel, so rounding x itself to 8 mantissa bits is noise of 5-10 % of the channel's SIGNAL, and the raw conv
+    output (stored in bf16 before its normalisation) carries the same offset.  Centred, both are rounded relative to the
+    signal.  Measured at configs[1] size: generated spectrogram bf16-vs-fp32 error 1.2e-1 -> see tests/test_gpu_fullsize.py."""
+    if net._dtype() != torch.bfloat16:
+        return x
+    first = _flat_conv_steps(net._steps(net._first_seq))[0].spec
+    if not (first.norm and first.pad_mode == 1):
+        return x
+    return x - x.mean(dim=(2, 3), keepdim=True)
+
+
 def _view(t_phys, channels):
     """Reference-shaped [N,C,H,W] view of a physical tensor; remembers the physical tensor for the HIP losses."""
     v = t_phys.permute(0, 3, 1, 2)[:, :channels]
@@ -353,8 +369,14 @@ class GlobalGenerator(_HipNet):
         first = [ids.index(id(_step_params(steps[j + 1])[0])) for j in cut_after]
         return cut_after, first
 
+    _first_seq = 'model'
+
+    def input_physical(self, x):
+        """NCHW f32 -> physical input of forward_physical (centred in bf16 mode, see _centered_input)."""
+        return self._to_phys(_centered_input(self, x))
+
     def forward(self, input):
-        return _ops.FromPhysical.apply(self.forward_physical(self._to_phys(input)), self.output_nc)
+        return _ops.FromPhysical.apply(self.forward_physical(self.input_physical(input)), self.output_nc)
 
 
 class LocalEnhancer(_HipNet):
@@ -395,8 +417,15 @@ class LocalEnhancer(_HipNet):
             out = _run(self._steps('model%d_2' % n), h)
         return out
 
+    _first_seq = 'model1_1'          # (the coarsest level's first layer has the same form: 7x7 behind ReflectionPad2d + InstanceNorm)
+
+    def input_physical(self, x):
+        """NCHW f32 -> physical input of forward_physical (centred in bf16 mode: the average pooling of the pyramid maps
+        a constant to the same constant, so every level sees its input shifted by it; see _centered_input)."""
+        return self._to_phys(_centered_input(self, x))
+
     def forward(self, input):
-        return _ops.FromPhysical.apply(self.forward_physical(self._to_phys(input)), self.output_nc)
+        return _ops.FromPhysical.apply(self.forward_physical(self.input_physical(input)), self.output_nc)
 
 
 class ResnetBlock(nn.Module):

@@ -300,10 +300,10 @@ class Pix2PixHDModel(BaseModel):
         _, cut_after, _ = self._bucket_plan()
         self._cuts = [] if cut_after else None
         if cut_after:
-            sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro), cuts=self._cuts,
+            sr_phys = self.netG.forward_physical(self.netG.input_physical(lr_spectro), cuts=self._cuts,
                                                  cut_after=set(cut_after))
         else:
-            sr_phys = self.netG.forward_physical(_ops.ToPhysical.apply(self.compute_dtype, lr_spectro))
+            sr_phys = self.netG.forward_physical(self.netG.input_physical(lr_spectro))
         sr_result = _ops.FromPhysical.apply(sr_phys, self.opt.output_nc)
 
         if share_fake_pass:

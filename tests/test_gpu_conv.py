@@ -449,7 +449,7 @@ def test_fused_backward_sums_need_the_callers_exclusive_flag():
     assert rel_err(x.grad.cpu().numpy(), xr.grad.numpy()) < 3e-4 and rel_err(w1.grad.cpu().numpy(), w1r.grad.numpy()) < 3e-4
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 16, 24, 4, 4), (2, 24, 16, 5, 7), (3, 40, 72, 32, 16), (1, 8, 8, 3, 9)])
 def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(shape, dtype, tol):
     """Input gradient of Conv3x3 behind ReflectionPad2d(1) (the residual trunk): the exact-grid form (dy extended by the
@@ -485,7 +485,7 @@ def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(sha
         assert rel_err(outs[0].numpy(), (x.grad + add).numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-6), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])   # (bias sums: float atomics, run-to-run order)
 def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypatch):
     """Producer without InstanceNorm (Conv + LeakyReLU, the discriminator's first layer): the exclusive consumer's
     input-gradient kernel multiplies dx by act'(x) (p2phd_conv_dgrad_act) and the producer skips its activation-backward

@@ -143,3 +143,59 @@ def test_three_scale_discriminator_against_reference(dtype, tol, gtol):
         assert len(nb) == 3 * 3
         for k, gr in zip(params.keys(), grads[1:]):
             assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol, noise_biases=nb)
+
+
+def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size():
+    """The benchmarked mode at the benchmarked geometry: configs[1]'s networks (real widths, 512x256, two samples) in bf16
+    against the SAME step in fp32 on the HIP path (itself checked against the oracle above): losses, generated spectrogram
+    and every weight gradient of both backward passes (what the direction-only checks on the 2-8-channel golden nets,
+    test_gpu_networks.py, cannot say about the real widths)."""
+    from oracle import model as OM
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    from pix2pixhdaudiosr_amd import _ops
+    oo = OM.default_opt(ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9, mask=False)
+    pG = OM.N.init_params(OM.netG_spec(oo), seed=1)
+    pD = OM.N.init_params(OM.netD_spec(oo), seed=2)
+    hr, lr, _ = OM.synthetic_batch(2, oo, seed=6)
+    res = {}
+    for name, fp16 in (("f32", False), ("bf16", True)):
+        m = create_model(_opt(fp16=fp16))
+        _load_from(m.netG, pG); _load_from(m.netD, pD)
+        _ops.bump_weight_epoch()
+        losses, sr = m.forward(lr, None, hr, None, infer=True)
+        got = dict(zip(m.loss_names, losses))
+        m.optimizer_G.zero_grad(); (got["G_GAN"] + got["G_GAN_Feat"]).backward(retain_graph=True)
+        gG = {k: p.grad.detach().float().cpu().clone() for k, p in m.netG.named_parameters()}
+        m.optimizer_D.zero_grad(); ((got["D_fake"] + got["D_real"]) * 0.5).backward()
+        gD = {k: p.grad.detach().float().cpu().clone() for k, p in m.netD.named_parameters()}
+        res[name] = ({k: float(v) for k, v in got.items()}, sr.detach().float().cpu(), gG, gD)
+        del m
+        torch.cuda.empty_cache()
+    (l32, sr32, gG32, gD32), (l16, sr16, gG16, gD16) = res["f32"], res["bf16"]
+    for k in l32:
+        assert abs(l16[k] - l32[k]) <= 2e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
+    e_sr = rel_err(sr16.numpy(), sr32.numpy())
+    worst = []
+    for tag, a, b in (("G", gG16, gG32), ("D", gD16, gD32)):
+        nb = noise_bias_keys(list(b))
+        for k, v in b.items():
+            if k.endswith(".weight"):
+                e = rel_err(a[k].numpy(), v.numpy())
+                c = float((a[k].double().flatten() @ v.double().flatten()) / max(float(a[k].double().norm() * v.double().norm()), 1e-300))
+                worst.append((e, c, f"{tag}:{k}"))
+    if os.environ.get("P2PHD_VERBOSE_TESTS"):
+        for e, c, name in worst:
+            print(f"   {name:36s} rel err {e:.3f} cosine {c:.4f}")
+    worst.sort(reverse=True)
+    print(f"bf16 vs fp32 at full size: sr rel err {e_sr:.2e}; worst weight-gradient rel err {worst[0][0]:.2e} ({worst[0][2]}), "
+          f"median {worst[len(worst) // 2][0]:.2e}, min cosine {min(c for _, c, _ in worst):.4f}")
+    # Measured (DESIGN.md 2): spectrogram 4.9e-2 (1.2e-1 before the generator input was centred, networks._centered_input);
+    # discriminator gradients 1-8 %; generator gradients 9 % at the output layer growing to 50 % (cosine 0.87) at the
+    # input layer -- not rounding of the gradient itself but ReLU masks: 3-5 % activation noise flips the branch of the
+    # ~2 % of elements that sit that close to zero, in every one of 28 layers, and each flip moves a gradient element by a
+    # full term.  bf16 has 8 mantissa bits; the reference's fp16 autocast has 11.
+    assert e_sr < 8e-2
+    d_err = [e for e, _, n in worst if n.startswith("D:")]
+    assert max(d_err) < 1.5e-1, max(d_err)
+    assert min(c for _, c, _ in worst) > 0.8
+    assert [e for e, _, n in worst if n == "G:model.38.weight"][0] < 1.5e-1
