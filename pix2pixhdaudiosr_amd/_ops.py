@@ -93,6 +93,8 @@ def _check_arena(ctx, device):
 
 # debugging hook: when a list, every conv block's backward appends (spec, g, dy, gx) clones (tools only)
 _BWD_TRACE = [None]
+# debugging hook: when a list, every normalised conv block's forward appends (spec, statistics clone, pixels per plane)
+_STATS_TRACE = [None]
 # number of forward convs that ran on the fp8 entry point (bench.py reports it with --fp8)
 _FP8_CALLS = [0]
 # number of InstanceNorm backward passes that took the sums from the consumer's input-gradient kernel
@@ -446,6 +448,8 @@ class ConvBlockFn(torch.autograd.Function):
         else:
             check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
         if spec.norm:
+            if _STATS_TRACE[0] is not None:
+                _STATS_TRACE[0].append((spec, stats.detach().clone(), Ho * Wo))
             res = None if residual is None else phys(residual, "residual")
             out = empty_like(y)
             if spec.emit_q8 and y.dtype == torch.bfloat16:
