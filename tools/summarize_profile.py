@@ -95,11 +95,41 @@ def derive(paths, out, trunk_out):
         print("wrote", trunk_out)
 
 
+def traffic(fetch_csv, write_csv, steps, out):
+    """Per-kernel memory-side bytes of one step from two --pmc passes (FETCH_SIZE, WRITE_SIZE) over the same eager run of
+    `steps` step-equivalents -> markdown table (profiles/r02_step_pmc_traffic.md)."""
+    acc = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0])            # launches, fetch KB, write KB, ns
+    for path, col in ((fetch_csv, 1), (write_csv, 2)):
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                k = short(r["Kernel_Name"])
+                acc[k][col] += float(r["Counter_Value"])
+                if col == 1:
+                    acc[k][0] += 1
+                    acc[k][3] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    rows = sorted(acc.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2]))
+    tot_r = sum(2 * v[1] for v in acc.values()) * 1024 / steps / 1e9
+    tot_w = sum(v[2] for v in acc.values()) * 1024 / steps / 1e9
+    with open(out, "w") as f:
+        f.write("# Memory-side traffic of one training step (configs[1], B=32, bf16), round 2\n\n"
+                "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a second pass, `--pmc WRITE_SIZE` on `python3 bench.py --steps 1 "
+                f"--warmup 1 --no-graph --no-cpu-baseline --no-mdct` ({steps} step-equivalents per pass); FETCH_SIZE x2 (gfx950 counts 64 B per "
+                "128-B request), WRITE_SIZE as is; Infinity-Cache hits included (upper bounds on HBM traffic); times are those of the "
+                "instrumented FETCH pass.\n\n"
+                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22).\n\n"
+                "| kernel | launches/step | read GB/step | written GB/step | time ms/step |\n|---|---|---|---|---|\n")
+        for k, v in rows[:40]:
+            f.write(f"| `{k[-70:]}` | {v[0] / steps:.1f} | {2 * v[1] * 1024 / steps / 1e9:.2f} | {v[2] * 1024 / steps / 1e9:.2f} | {v[3] / steps / 1e6:.2f} |\n")
+    print("wrote", out, f"read {tot_r:.1f} GB written {tot_w:.1f} GB per step")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--trace"); ap.add_argument("--pmc", nargs="*"); ap.add_argument("--derive", nargs="*")
-    ap.add_argument("--trunk-out"); ap.add_argument("--out", required=True)
+    ap.add_argument("--trunk-out"); ap.add_argument("--traffic", nargs=2); ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--out", required=True)
     a = ap.parse_args()
     if a.trace: trace(a.trace, a.out)
+    elif a.traffic: traffic(a.traffic[0], a.traffic[1], a.steps, a.out)
     elif a.derive: derive(a.derive, a.out, a.trunk_out)
     else: pmc(a.pmc, a.out)
