@@ -94,6 +94,31 @@ def time_graphed(call, iters=20):
     return best
 
 
+def time_generator(model, batch):
+    """GlobalGenerator forward + backward alone (north_star target: >= 40 % MFMA on G fwd+bwd at 512x256 bf16): the
+    generator of the benchmarked model on a [B,2,512,256] input, every weight gradient into the flat buffer, captured into a
+    HIP graph and timed with events.  Algorithmic work: 6 M_G FLOP per sample (forward + input gradients + weight
+    gradients; the first layer has no input gradient -- stated in the JSON)."""
+    from pix2pixhdaudiosr_amd import _ops
+    netG, optG = model.netG, model.optimizer_G
+    x = torch.rand(batch, 2, 512, 256, device="cuda")
+    gy = None
+
+    def call():
+        nonlocal gy
+        _ops.begin_step(model.device)
+        y = netG.forward_physical(netG.input_physical(x))
+        _ops.end_arena(model.device)
+        if gy is None:
+            gy = (torch.randn(y.shape, device="cuda") * 1e-3).to(y.dtype)
+            gy[..., 2:] = 0
+        y.backward(gy, inputs=list(optG._params))
+
+    sec = time_graphed(call, iters=3)
+    optG.zero_grad()
+    return sec
+
+
 HBM_PEAK_TBS = 8.0                # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s float4-copy achievable)
 
 
@@ -130,25 +155,47 @@ def host_cores():
     return max(1, min(n, 16))          # a 1-GPU box's CPU share is 16 cores
 
 
-def cpu_baseline(sample_batch=2, steps=4):
-    """The CPU oracle (oracle/model.py full_step: a port of the reference step, validated against the reference in
-    tests/) on the host cores, same workload at a bounded batch."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _cpu_leg(ngf, sample_batch, steps):
     from oracle import model as OM
     from oracle import mdct4 as M4
-    opt = OM.default_opt(ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9)
-    torch.set_num_threads(host_cores())
+    opt = OM.default_opt(ngf=ngf, netG="global", n_downsample_global=4, n_blocks_global=9)
     pG = OM.N.init_params(OM.netG_spec(opt), seed=1)
     pD = OM.N.init_params(OM.netD_spec(opt), seed=2)
     hr, lr, noise = OM.synthetic_batch(sample_batch, opt)
     w = M4.kbdwin(opt.win_length)
     sG, sD = {}, {}
+    _, pG, pD = OM.full_step(hr, lr, noise, pG, pD, opt, w, sG, sD)           # one warm-up step
     t0 = time.time()
     for _ in range(steps):
         _, pG, pD = OM.full_step(hr, lr, noise, pG, pD, opt, w, sG, sD)
     dt = (time.time() - t0) / steps
-    return {"value": sample_batch * FRAMES / dt, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle full_step (CPU port of train.py:148-184), same network/config at batch {sample_batch}, "
-                      f"{steps} timed step(s), fp32, {dt:.2f} s/step"}
+    return sample_batch * FRAMES / dt, dt
+
+
+def cpu_baseline(sample_batch=2, steps=3):
+    """The CPU oracle (oracle/model.py full_step: a port of the reference step, validated against the reference in
+    tests/) on the host cores: the benchmarked workload (configs[1]'s networks) and the reference's own CPU-runnable case
+    (configs[0]: ngf 32), each at batch 2, 1 warm-up + 3 timed steps."""
+    torch.set_num_threads(host_cores())
+    v1, dt1 = _cpu_leg(48, sample_batch, steps)
+    v0, dt0 = _cpu_leg(32, sample_batch, steps)
+    return {"value": v1, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_name(),
+            "sample": f"oracle full_step (CPU port of train.py:148-184), configs[1]'s network/config at batch {sample_batch}, "
+                      f"1 warm-up + {steps} timed step(s), fp32, {dt1:.2f} s/step",
+            "configs0": {"value": v0, "unit": "frames/s",
+                         "sample": f"same step with configs[0]'s generator (ngf 32) at batch {sample_batch}, {dt0:.2f} s/step"}}
 
 
 def _free_port():
@@ -188,6 +235,8 @@ def main():
     ap.add_argument("--allow-eager-fallback", action="store_true",
                     help="keep measuring with the eager step if graph capture / replay fails (default: exit non-zero)")
     ap.add_argument("--no-mdct", action="store_true", help="skip the stand-alone MDCT4 / IMDCT4 measurement")
+    ap.add_argument("--comm-cus", type=int, default=0,
+                    help="data parallel: run the step on a stream whose CU mask leaves this many CUs to the RCCL kernels (0 = off)")
     ap.add_argument("--fp8", action="store_true",
                     help="variant of BASELINE configs[4]: e4m3 forward of the wide stride-1 convs on top of bf16 (NOT the headline dtype)")
     a = ap.parse_args()
@@ -230,6 +279,7 @@ def main():
     torch.manual_seed(1234)                      # same initial weights on every rank (reference default seed)
     opt = make_opt(a.batch, fp8=a.fp8)
     opt.gpu_ids = [local]
+    opt.comm_cus = a.comm_cus
     model = create_model(opt)
     if rehearse:
         opt.grad_buckets = 4
@@ -288,11 +338,16 @@ def main():
             torch.cuda.synchronize()
         log(f"warm-up step {i} done")
     barrier()
+    for o_ in (model.optimizer_G, model.optimizer_D):
+        o_.reset_exchange_timing(dist_on)                          # events around every wait for a collective (N > 1 / rehearsal)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step(lr, hr)
     barrier()
     dt = time.perf_counter() - t0
+    exch = {"G": model.optimizer_G.exchange_timing(), "D": model.optimizer_D.exchange_timing()} if dist_on else None
+    for o_ in (model.optimizer_G, model.optimizer_D):
+        o_.reset_exchange_timing(False)
     rank_ms = [dt / a.steps * 1e3]
     dist_info = None
     if dist_on:
@@ -303,8 +358,22 @@ def main():
         rank_ms = [float(v.item()) / a.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # exposed exchange: time the COMPUTE stream stood still in wait_gradients() (events around the waits), per step,
+        # max over ranks; host_wait_ms is the host-side blocking of the same waits (gloo)
+        ex = torch.tensor([exch["G"]["exposed_stream_ms"] / a.steps, exch["D"]["exposed_stream_ms"] / a.steps,
+                           (exch["G"]["host_wait_ms"] + exch["D"]["host_wait_ms"]) / a.steps], device="cuda", dtype=torch.float64)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        gb = [int(b - a) for a, b in model.optimizer_G.bucket_log]
         dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rehearsal_one_rank": rehearse,
-                     "g_gradient_buckets": [int(b - a) for a, b in model.optimizer_G.bucket_log],
+                     "g_gradient_buckets": gb,
+                     "bucket_bytes": {"G": [4 * n for n in gb], "D": [4 * int(model.optimizer_D._total)]},
+                     "gradient_dtype_on_the_wire": "fp32",
+                     "exposed_exchange_ms": float(ex[0] + ex[1]), "exposed_exchange_ms_G": float(ex[0]),
+                     "exposed_exchange_ms_D": float(ex[1]), "host_wait_ms": float(ex[2]),
+                     "waits_per_step": (exch["G"]["waits"] + exch["D"]["waits"]) / a.steps,
+                     "exposed_how": "HIP events on the compute stream around every wait for a collective (optim.FlatAdam.wait_gradients): "
+                                    "the G buckets are waited for after the D backward, the D bucket after the generator's Adam",
+                     "comm_cus": a.comm_cus,
                      "devices": sorted({local}) if "P2PHD_FORCE_DEVICE" in os.environ else list(range(world))}
 
     if rank == 0:
@@ -340,7 +409,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
         # from the separate rocprofv3 --pmc passes recorded in profiles/ (same kernel, same shapes, per launch)
         traffic, traffic_source = None, None
-        for name in ("r02_trunk_pmc.json", "r01_trunk_pmc.json"):
+        for name in ("r03_trunk_pmc.json", "r02_trunk_pmc.json", "r01_trunk_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     rec = json.load(f)
@@ -356,39 +425,62 @@ def main():
         from pix2pixhdaudiosr_amd import _ops
         sec_iso, flops = time_trunk_conv(a.batch)
         sec = sec_iso
+        sec_dgrad = None
         if world == 1:                                             # extra steps on one rank only would desynchronise the collectives
             import ctypes as C
             L = _ops.lib()
-            # events around the gconv launches of the trunk layer only (cin pitch 768, GEMM-K 9 * 768, 32 x 16 grid), on
-            # their launch stream, inside two extra eager steps: forward launches AND the same-shaped launches of the
-            # backward pass are excluded by shape (the input gradient runs on the padded 34 x 18 grid)
-            _ops.check(L.p2phd_probe_gconv(1, 768, 9 * 768, 32, 16))
-            for _ in range(2):
-                model.train_step(lr, hr)
-            torch.cuda.synchronize()
-            buf = (C.c_float * 4096)()
-            n_ev = L.p2phd_probe_read(buf, 4096)
-            _ops.check(L.p2phd_probe_gconv(0, 0, 0, 0, 0))
-            if n_ev:
-                sec = sum(buf[i] for i in range(n_ev)) / n_ev / 1e3
-                log(f"trunk conv inside the step: {sec * 1e6:.1f} us/launch over {n_ev} launches "
+
+            def probe(pad_mode, esize):
+                # events around the gconv launches of the trunk layer only (cin pitch 768, GEMM-K 9 * 768, 32 x 16 grid), on
+                # their launch stream, inside two extra eager steps.  The forward (reflect gather, pad_mode 1) and the
+                # input gradient (reflect adjoint, pad_mode 2) run on the same grid and are told apart by the gather's
+                # padding rule; `esize` tells the e4m3 forward of --fp8 from bf16 launches
+                _ops.check(L.p2phd_probe_gconv_ex(1, 768, 9 * 768, 32, 16, pad_mode, esize))
+                for _ in range(2):
+                    model.train_step(lr, hr)
+                torch.cuda.synchronize()
+                buf = (C.c_float * 4096)()
+                n_ev = L.p2phd_probe_read(buf, 4096)
+                _ops.check(L.p2phd_probe_gconv_ex(0, 0, 0, 0, 0, -1, 0))
+                return (sum(buf[i] for i in range(n_ev)) / n_ev / 1e3, n_ev) if n_ev else (None, 0)
+
+            got, n_ev = probe(1, 1 if a.fp8 else 2)
+            if got is not None:
+                sec = got
+                log(f"trunk conv FORWARD inside the step: {sec * 1e6:.1f} us/launch over {n_ev} launches "
                     f"(stand-alone conv_fwd incl. statistics merge, back-to-back: {sec_iso * 1e6:.1f} us)")
+            sec_dgrad, n_dg = probe(2, 2)
+            if sec_dgrad is not None:
+                log(f"trunk conv INPUT GRADIENT inside the step: {sec_dgrad * 1e6:.1f} us/launch over {n_dg} launches")
         log(f"trunk conv {sec * 1e6:.1f} us/launch")
         out["roofline"] = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                           "kernel": "gconv_kernel<bf16> implicit-GEMM Conv3x3 768->768 @32x16 (residual trunk, 18 of 28 generator convs)",
-                           "launch_us": sec * 1e6, "flops_per_launch": flops}
+                           "kernel": "gconv_kernel<bf16> implicit-GEMM Conv3x3 768->768 @32x16, forward (residual trunk, 18 of 28 generator convs)",
+                           "launch_us": sec * 1e6, "flops_per_launch": flops,
+                           "launches_timed": "forward launches only (gather pad_mode 1); the same-shaped input-gradient launches: dgrad_launch_us",
+                           "dgrad_launch_us": None if sec_dgrad is None else sec_dgrad * 1e6}
         if a.fp8 and world == 1:
             # the probed launches are the e4m3 forward of the trunk: price them against the dense fp8 peak, and the
             # recorded HBM traffic (taken on the bf16 kernel) does not apply
             out["roofline"].update({"peak": FP8_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / FP8_DENSE_PEAK_TFLOPS,
                                     "traffic": None, "traffic_source": None,
                                     "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
+        if world == 1:
+            try:
+                tg = time_generator(model, a.batch)
+                gf = 6 * M_G * a.batch
+                out["config"].update({"G_fwd_bwd_ms": tg * 1e3, "G_fwd_bwd_tflops": gf / tg / 1e12,
+                                      "G_fwd_bwd_frac_of_bf16_peak": gf / tg / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+                                      "G_fwd_bwd_how": "GlobalGenerator forward + backward alone (all weight gradients), graph replay, HIP "
+                                                       "events; 6 M_G FLOP per sample, convs only (InstanceNorm passes are in the time)"})
+                log(f"generator fwd+bwd alone: {tg * 1e3:.2f} ms = {gf / tg / 1e12:.0f} TFLOP/s")
+            except Exception as e:                                 # a measurement extra: never lose the headline line to it
+                log(f"generator-only timing failed: {type(e).__name__}: {e}")
         if world == 1 and not a.no_mdct:
             out["mdct"] = time_mdct(a.batch)
             log("mdct alone: " + ", ".join(f"{k} {v['us']:.1f} us {v['GB_per_s']:.0f} GB/s" for k, v in out["mdct"].items()))
         if world == 1 and not a.no_cpu_baseline:
-            log("cpu baseline (oracle, batch 2, 4 steps) ...")
+            log("cpu baseline (oracle, batch 2: configs[1] and configs[0] networks, 1 + 3 steps each) ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if dist_on:

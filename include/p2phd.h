@@ -46,6 +46,10 @@ int p2phd_set_option(const char* name, int value);
  * own launch stream (the kernel alone: none of the companion launches of p2phd_conv_fwd).  p2phd_probe_read waits for
  * the recorded events and returns up to `cap` durations in milliseconds; arm with enable = 0 to stop. */
 int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg);
+/* Same with two more filters: gather_pad_mode = the padding rule of the launch's gather (0 zeros, 1 reflect = the forward of
+ * a ReflectionPad2d conv, 2 = the reflect adjoint of its input gradient; -1 = any) and elem_bytes = operand element size
+ * (1 e4m3, 2 bf16, 4 f32; 0 = any) -- so a forward launch is told from the same-shaped input-gradient launch. */
+int p2phd_probe_gconv_ex(int enable, int cin_pitch, int kk, int hg, int wg, int gather_pad_mode, int elem_bytes);
 int p2phd_probe_read(float* ms_out, int cap);
 
 /* ------------------------------------------------------------------------------------------

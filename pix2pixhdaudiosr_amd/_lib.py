@@ -23,6 +23,7 @@ SIGNATURES = {
     "p2phd_device_info": (_i32, [C.c_char_p, _i32]),
     "p2phd_set_option": (_i32, [C.c_char_p, _i32]),
     "p2phd_probe_gconv": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "p2phd_probe_gconv_ex": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_read": (_i32, [_vp, _i32]),
     "p2phd_mdct4_tables_floats": (C.c_size_t, [_i32]),
     "p2phd_mdct4_tables_fill": (_i32, [_i32, _vp]),

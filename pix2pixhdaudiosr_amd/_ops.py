@@ -131,6 +131,30 @@ def backward_without_input_grads(specs):
         _BWD_SKIP_DGRAD_SPECS.difference_update(ids)
 
 
+# Backward over a SAMPLE RANGE of a batch (Pix2PixHDModel: D(real) and D(fake) run as ONE batch of 2B samples -- real
+# half first -- and the generator-loss pass only has a gradient on the fake half).  While set, every backward Function of
+# this module whose batch size is `n_full` processes samples [lo, hi) only: it launches its kernels on the contiguous
+# sub-batch views (NHWC is sample-major) and leaves the rest of the gradient tensor it returns UNWRITTEN -- the next
+# Function up the chain is restricted the same way, and the chain ends in ToPhysicalPair.backward, which reads the fake half.
+_BWD_RANGE = {"n_full": None, "lo": 0, "hi": 0}
+
+
+@contextlib.contextmanager
+def backward_on_samples(n_full, lo, hi):
+    prev = dict(_BWD_RANGE)
+    _BWD_RANGE.update(n_full=int(n_full), lo=int(lo), hi=int(hi))
+    try:
+        yield
+    finally:
+        _BWD_RANGE.update(prev)
+
+
+def _bwd_range(n):
+    if _BWD_RANGE["n_full"] is not None and _BWD_RANGE["n_full"] == int(n):
+        return _BWD_RANGE["lo"], _BWD_RANGE["hi"]
+    return None
+
+
 def _direct_grad(p):
     """True when `p.grad` is FlatAdam's view of its flat gradient buffer (optim.py marks the parameter)."""
     g = p.grad
@@ -316,6 +340,28 @@ class ToPhysical(torch.autograd.Function):
         return (None, *grads)
 
 
+class ToPhysicalPair(torch.autograd.Function):
+    """Two channel-concatenated NCHW inputs stacked along the batch: out[:B] = cat(a, b_real), out[B:] = cat(a, b_fake)
+    (the discriminator's input for D(real) and D(fake) as one batch of 2B).  Only b_fake gets a gradient."""
+
+    @staticmethod
+    def forward(ctx, dtype, a, b_real, b_fake):
+        B, ca, H, W = a.shape
+        cb = int(b_real.shape[1])
+        out = empty((2 * B, H, W, cpitch(ca + cb)), dtype, a.device).zero_()
+        for half, other in ((out[:B], b_real), (out[B:], b_fake)):
+            to_physical(a, dtype, out=half, ch_off=0)
+            to_physical(other, dtype, out=half, ch_off=ca)
+        ctx.meta = (B, ca, cb)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, ca, cb = ctx.meta
+        g = g.contiguous()
+        return None, None, None, (from_physical(g[B:], cb, ca) if ctx.needs_input_grad[3] else None)
+
+
 class FromPhysical(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_phys, channels):
@@ -487,13 +533,35 @@ class ConvBlockFn(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
+        rng = _bwd_range(d.N)
+        x_full = x
+        if rng is not None:
+            # sample-range backward (see backward_on_samples): everything below runs on the sub-batch views
+            lo, hi = rng
+            x, y, g = x[lo:hi], y[lo:hi], g[lo:hi]
+            stats = None if stats is None else stats[lo:hi]
+            d = spec.desc(hi - lo, x.shape[1], x.shape[2], x.dtype)
         parked, ctx._parked = ctx._parked, None
         dy_done, ctx._dy_done = ctx._dy_done, None                 # (consumed once: a marker must not outlive its backward pass)
+        # the consumer's input-gradient kernel (p2phd_conv_dgrad_act) may have applied this block's activation derivative
+        # to g already; that is only usable when g IS the tensor it wrote (same storage, untouched since)
+        carries_act = False
+        if dy_done is not None:
+            if not (dy_done == (g.data_ptr(), g._version) and g.shape == y.shape and not spec.norm and spec.act != ACT_NONE):
+                raise _lib.P2PHDError("conv backward: the consumer's input-gradient kernel already applied this block's activation "
+                                      "derivative, but the gradient that arrived is not the tensor it wrote (a second consumer of "
+                                      "an `exclusive` chain?); rerun with P2PHD_BSUM=0")
+            carries_act = True
         if parked is not None:
-            dy_done = None
             # a loss parked its gradient of this block's output for the consumer's input-gradient kernel to add, and that
             # kernel did not take it (it ran first, or does not exist in this backward pass): add it here
-            g = g + parked.to(g.dtype)
+            parked = parked.to(g.dtype)
+            if carries_act:
+                # g is already dL/d(pre-activation) of the conv path; the parked part is still dL/d(output): give it act' alone
+                pk = empty_like(y)
+                check(L.p2phd_act_bwd(d.dtype, ptr(parked.contiguous()), ptr(y), ptr(pk), y.numel(), spec.act, stream_ptr()), "act_bwd")
+                parked = pk
+            g = g + parked
             ctx._bs = None
         N, Ho, Wo, Cp_out = y.shape
         need_w = ((ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])) and not ctx.skip_wgrad
@@ -520,7 +588,7 @@ class ConvBlockFn(torch.autograd.Function):
                 check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
                           stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
-        elif spec.act != ACT_NONE and dy_done is not None and dy_done == (g.data_ptr(), g._version) and g.shape == y.shape:
+        elif carries_act:
             dy = g                                                 # the consumer's input-gradient kernel applied act' already
             _BSUM_CALLS[0] += 1
         elif spec.act != ACT_NONE:
@@ -550,9 +618,11 @@ class ConvBlockFn(torch.autograd.Function):
                 check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
             if direct:
                 gw = gb = None
+        gx_full = None
         if ctx.needs_input_grad[0] and id(spec) not in _BWD_SKIP_DGRAD_SPECS:
             wp = spec.packed(weight, 1, d)
-            gx = empty_like(x)
+            gx_full = empty_like(x_full)
+            gx = gx_full if rng is None else gx_full[rng[0]:rng[1]]
             wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))
             ws = workspace(wsb, y.device) if wsb else None
             # first conv of a residual block: the skip gradient parked by the block's second conv is added inside the
@@ -564,24 +634,32 @@ class ConvBlockFn(torch.autograd.Function):
             if src is not None and src._parked is not None and src._p2phd_consumers == 1:
                 # feature-matching gradient of x parked by the loss: summed inside this kernel instead of by autograd
                 pk, src._parked = src._parked, None
+                if pk.shape != gx.shape:
+                    raise _lib.P2PHDError(f"conv backward: a parked loss gradient of shape {tuple(pk.shape)} meets an input gradient of "
+                                          f"shape {tuple(gx.shape)} (a half-batch loss needs backward_on_samples around this pass)")
                 addend = pk if addend is None else addend + pk
-            fuse = (src is not None and src.spec.norm and src._p2phd_consumers == 1 and _bsum_enabled() and src.y is not None
-                    and src.y.shape == x.shape and src.y.dtype == x.dtype and src.spec.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
+            src_y = src_stats = None
+            if src is not None and src.y is not None:
+                src_y = src.y if rng is None else src.y[rng[0]:rng[1]]
+                if src.stats is not None:
+                    src_stats = src.stats if rng is None else src.stats[rng[0]:rng[1]]
+            fuse = (src is not None and src.spec.norm and src._p2phd_consumers == 1 and _bsum_enabled() and src_y is not None
+                    and src_y.shape == x.shape and src_y.dtype == x.dtype and src.spec.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
                     and L.p2phd_instnorm_act_bwd_two_pass(d.dtype, x.shape[0], x.shape[1] * x.shape[2], spec.cin)
                     and L.p2phd_conv_dgrad_bsum_ok(C.byref(d)))
             if fuse:
                 _check_arena(src, y.device)
                 bst = empty((x.shape[0], x.shape[3], 2), torch.float32, y.device)
                 wsf = workspace(max(L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 256), y.device)
-                check(L.p2phd_conv_dgrad_bsum(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src.y), ptr(src.stats),
+                check(L.p2phd_conv_dgrad_bsum(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src_y), ptr(src_stats),
                                               src.spec.act, IN_EPS, ptr(bst), ptr(wsf), stream_ptr()), "conv_dgrad_bsum")
                 src._bs = (bst, gx.data_ptr(), gx._version)
             elif (src is not None and not src.spec.norm and src.spec.act in (ACT_RELU, ACT_LRELU) and src._p2phd_consumers == 1
-                  and _bsum_enabled() and src.y is not None and src.y.shape == x.shape and src.y.dtype == x.dtype
+                  and _bsum_enabled() and src_y is not None and src_y.shape == x.shape and src_y.dtype == x.dtype
                   and L.p2phd_conv_dgrad_bsum_ok(C.byref(d))):
                 # producer = Conv + (Leaky)ReLU without normalisation: its activation derivative is applied to gx here
                 wsf = workspace(max(L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 256), y.device)
-                check(L.p2phd_conv_dgrad_act(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src.y), src.spec.act, ptr(wsf),
+                check(L.p2phd_conv_dgrad_act(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src_y), src.spec.act, ptr(wsf),
                                              stream_ptr()), "conv_dgrad_act")
                 src._dy_done = (gx.data_ptr(), gx._version)
             else:
@@ -589,9 +667,11 @@ class ConvBlockFn(torch.autograd.Function):
         if _BWD_TRACE[0] is not None:
             _BWD_TRACE[0].append((spec, g.detach().clone(), dy.detach().clone(), None if gx is None else gx.detach().clone()))
         gres = g if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        if gres is not None and rng is not None:
+            raise _lib.P2PHDError("sample-range backward through a residual block is not supported")
         if gres is not None and ctx.link is not None and ctx.link.park(gres, ctx):
             gres = None
-        return gx, gw, gb, gres, None, None, None
+        return gx_full, gw, gb, gres, None, None, None
 
 
 class SkipLink:
@@ -647,6 +727,11 @@ class AvgPoolFn(torch.autograd.Function):
         N, H, W, Cp, channels = ctx.meta
         g = g.contiguous()
         dx = empty((N, H, W, Cp), g.dtype, g.device)
+        rng = _bwd_range(N)
+        if rng is not None:                                        # sample-range backward (backward_on_samples)
+            lo, hi = rng
+            check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
+            return dx, None
         check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
         return dx, None
 
@@ -660,49 +745,72 @@ def avgpool(x, channels):
 # ------------------------------------------------------------------------------------------
 
 class LossFn(torch.autograd.Function):
-    """kind 0: mean((a-target)^2) ; kind 1: mean(|a-b|) * coeff.  Returns a 0-dim f32 device tensor."""
+    """kind 0: mean((a-target)^2) ; kind 1: mean(|a-b|) * coeff.  Returns a 0-dim f32 device tensor.
+    `rows` = (n0, n1): the loss is taken over samples [n0, n1) of `a` only (b, if given, has n1 - n0 samples); the
+    gradient is zero on the other samples -- or, with park, only the [n0, n1) part exists and is parked."""
 
     @staticmethod
-    def forward(ctx, a, b, kind, target, coeff, channels, park=False):
+    def forward(ctx, a, b, kind, target, coeff, channels, park=False, rows=None):
         gf = getattr(a, "grad_fn", None)
         ctx.park_src = gf if (park and gf is not None and hasattr(gf, "_p2phd_consumers") and hasattr(gf, "_parked")) else None
         if ctx.park_src is None:
             _note_consumer(a)
         a = phys(a, "loss input")
-        P = a.numel() // a.shape[-1]
+        av = a if rows is None else a[rows[0]:rows[1]]
+        if b is not None and tuple(b.shape) != tuple(av.shape):
+            raise _lib.P2PHDError(f"loss: operand shapes differ: {tuple(av.shape)} vs {tuple(b.shape)}")
+        P = av.numel() // av.shape[-1]
         out = zeros((), a.device)
-        check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(a), ptr(b), float(target), P, channels, float(coeff),
+        check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(av), ptr(b), float(target), P, channels, float(coeff),
                                    ptr(out), stream_ptr()), "loss_fwd")
-        ctx.meta = (kind, float(target), float(coeff), channels, P)
+        ctx.meta = (kind, float(target), float(coeff), channels, P, rows)
         ctx.a, ctx.b = a, b
         return out
 
     @staticmethod
     def backward(ctx, g):
-        kind, target, coeff, channels, P = ctx.meta
+        kind, target, coeff, channels, P, rows = ctx.meta
         a, b = ctx.a, ctx.b
-        da = empty_like(a)
+        av = a if rows is None else a[rows[0]:rows[1]]
+        parked = ctx.park_src is not None
+        if rows is None or parked:
+            da_full = None
+            da = empty_like(av)
+        else:
+            da_full = torch.zeros_like(a)                          # (last-stage features: a few hundred KB)
+            da = da_full[rows[0]:rows[1]]
         g = g.contiguous().float()
-        check(lib().p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(a), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
+        check(lib().p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(av), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
                                    stream_ptr()), "loss_bwd")
         if _BWD_TRACE[0] is not None:
-            _BWD_TRACE[0].append((("loss", kind, tuple(a.shape), coeff), g.detach().clone(), da.detach().clone(),
+            _BWD_TRACE[0].append((("loss", kind, tuple(av.shape), coeff), g.detach().clone(), da.detach().clone(),
                                   None if b is None else b.detach().clone()))
-        if ctx.park_src is not None:
+        if parked:
             # hand the gradient to the block that produced `a`: its exclusive consumer adds it inside its input-gradient
             # kernel (or the block itself does, if that kernel is not part of this backward pass); autograd gets nothing
             src = ctx.park_src
             src._parked = da if src._parked is None else src._parked + da
-            return None, None, None, None, None, None, None
-        return da, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
+        return (da if da_full is None else da_full), None, None, None, None, None, None, None
 
 
-def mse_const_loss(a_phys, channels, target):
-    return LossFn.apply(a_phys, None, 0, target, 1.0, channels)
+def mse_const_loss(a_phys, channels, target, rows=None):
+    return LossFn.apply(a_phys, None, 0, target, 1.0, channels, False, rows)
 
 
 def l1_loss(a_phys, b_phys, channels, coeff=1.0, park=False):
     """`park`: a_phys is the output of a conv block whose only other consumer is the next conv block of an exclusive chain
     (networks._run): the loss gradient is parked on the producer and added inside that consumer's input-gradient kernel
     instead of by an autograd accumulation launch (and the InstanceNorm-backward sums can be fused there, see _bsum_enabled)."""
-    return LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels, park)
+    return LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels, park, None)
+
+
+def l1_halves_loss(t_phys, channels, coeff=1.0, park=False):
+    """mean(|t[B:] - t[:B]|) * coeff for a tensor holding two stacked batches (real half first, then fake): the
+    feature-matching term when D(real) and D(fake) ran as one batch.  The gradient exists on the fake half only; with
+    `park` it is parked (half-shaped) on the producer for the consumer's input-gradient kernel of a sample-range
+    backward pass (backward_on_samples) to add."""
+    n = t_phys.shape[0]
+    if n % 2:
+        raise _lib.P2PHDError("l1_halves_loss: the batch must hold two equal halves")
+    return LossFn.apply(t_phys, t_phys.detach()[:n // 2], 1, 0.0, coeff, channels, park, (n // 2, n))

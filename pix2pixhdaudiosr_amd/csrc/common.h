@@ -35,6 +35,43 @@ int mdct4_fast_fwd(const float* x, int64_t B, int64_t T, int n_fft, const float*
 int imdct4_fast(const float* spec, int64_t B, int64_t n_frames, int n_fft, const float* window, const float* tables,
                 int64_t crop, int64_t out_len, float scale, float* out, hipStream_t st);
 
+// ---- fixed-order reductions across workgroups (no float atomics) -------------------------------------------------
+// "Last workgroup folds": every workgroup of a group stores its partial row into a slice of a library-owned scratch
+// (`sc1` write-through stores: the per-XCD L2s are not coherent with each other), takes a ticket of the group with an
+// agent-scope integer atomic, and the workgroup that drew the last ticket sums the rows in index order -- the result
+// does not depend on which workgroup finishes when.  The scratch is a `__device__` array of the code object (no
+// allocation in any entry point); one region per kernel family, so the families may run on different streams, but two
+// launches of the SAME family must be ordered (one compute stream per process, as everywhere in this library).
+enum FoldRegion { FOLD_IN_BWD = 0, FOLD_COLSUM = 1, FOLD_ACT_DB = 2, FOLD_LOSS = 3, FOLD_GCONV = 4 };
+struct FoldScratch { float* part; unsigned* ticket; size_t floats; int tickets; };
+FoldScratch fold_scratch(int region);
+
+#ifdef __HIPCC__
+__device__ __forceinline__ void fold_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fold_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// True in exactly one workgroup of the `expected` that call this on `ticket`: the one that arrived last.  All its threads
+// may then fold_load() what the others fold_store()d before arriving.  Re-arms the ticket for the next launch.
+__device__ __forceinline__ bool fold_arrive_last(unsigned* ticket, unsigned expected) {
+  __shared__ unsigned s_fold_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's partial stores have left
+  __syncthreads();                                              // ... and every other wave's of the workgroup
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = t + 1u == expected;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_fold_last = last ? 1u : 0u;
+  }
+  __syncthreads();
+  const bool last = s_fold_last != 0u;
+  if (last) {                                                   // uniform over the workgroup
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");          // belt and braces beside the sc1 loads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  return last;
+}
+#endif
+
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -125,10 +125,21 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   // are wanted and the per-sample pixel count does not fill whole tiles, flat over all N * npix pixels
   const bool flat = d.flat_m != 0;
   const int mtiles = (npix + BM - 1) / BM;
-  const int n = flat ? 0 : blockIdx.x / mtiles;
-  const int p_base = flat ? blockIdx.x * BM : (blockIdx.x - n * mtiles) * BM;
+  // 1-D launch: workgroups [0, sk_first) are whole tiles (tile = id); from sk_first on, the LAST tiles of the grid -- the
+  // ones that would have run as an almost empty extra round of the 256 CUs -- are cut along K into sk_parts workgroups each
+  // (workgroup sk_first + part * tail + i works on tile sk_first + i, K slabs [part * sk_steps, ...)): see launch_gconv_cfg.
+  int tile_id = (int)blockIdx.x, sk_part = -1, sk_tile = 0;
+  if (tile_id >= d.sk_first) {
+    const int r = tile_id - d.sk_first;
+    sk_part = r / d.sk_tail;
+    sk_tile = r - sk_part * d.sk_tail;
+    tile_id = d.sk_first + sk_tile;
+  }
+  const int bx = tile_id % d.grid_m, by = tile_id / d.grid_m;
+  const int n = flat ? 0 : bx / mtiles;
+  const int p_base = flat ? bx * BM : (bx - n * mtiles) * BM;
   const int p_end = flat ? d.N * npix : npix;                 // rows >= p_end are padding
-  const int n0 = blockIdx.y * BN;
+  const int n0 = by * BN;
 
   {  // row table (the only integer divisions of the kernel: one or two per tile row), then the gather table
     // input pixel index (or -1) per (tap, tile row): each thread walks its row's taps with counters
@@ -182,7 +193,15 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const int rbase = tid >> 3;                                 // rows rbase + RS i
   const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);          // logical 16-byte chunk of the K slab
   const int CpB = Cp * SZ;
-  int a_t = (kchunk * EPP) / Cp, a_cB = ((kchunk * EPP) % Cp) * SZ;
+  const int nsteps_all = KK / BK;
+  const int s_begin = sk_part < 0 ? 0 : sk_part * d.sk_steps;     // first K slab of this workgroup
+  const int nsteps = sk_part < 0 ? nsteps_all : min(d.sk_steps, nsteps_all - s_begin);
+  int a_t, a_cB;
+  {
+    const long kb = (long)kchunk * EPP * SZ + (long)s_begin * kRowBytes;   // byte position of this thread's chunk in the K row
+    a_t = (int)(kb / CpB);
+    a_cB = (int)(kb - (long)a_t * CpB);
+  }
   int cur_t = -1;
   unsigned aoffb[NA], va[NA];
 #pragma unroll
@@ -328,13 +347,12 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         if (i * NR + j >= skip) mfma_one(buf, i, j);
   };
 
-  const int nsteps = KK / BK;
 #pragma unroll
   for (int t = 0; t < NSTAGE; ++t) {
     if (t < nsteps) {
       prepare();
 #pragma unroll
-      for (int j = 0; j < NLOADS; ++j) issue_piece(t, t, j);
+      for (int j = 0; j < NLOADS; ++j) issue_piece(t, s_begin + t, j);
     }
   }
 #ifdef P2PHD_PROBE_FINE
@@ -401,8 +419,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       if (ks == 3 && issue_new) {
         prepare();
 #pragma unroll
-        for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, s + NSTAGE, j);
-        pend = true; pend_slot = cur; pend_tile = s + NSTAGE;
+        for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, s_begin + s + NSTAGE, j);
+        pend = true; pend_slot = cur; pend_tile = s_begin + s + NSTAGE;
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -418,6 +436,52 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const unsigned long long pr_t2 = __builtin_readcyclecounter();
 #endif
   __syncthreads();
+
+  if (sk_part >= 0) {
+    // Split tile: every part stores its raw accumulators (float4 pieces, lane-interleaved: coalesced), takes a ticket of
+    // the tile, and the part that arrives LAST adds all parts in index order -- a fixed summation order whatever the
+    // timing -- and carries on into the normal epilogue.  sc1 stores / loads: the parts run on different XCDs.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    constexpr int NQ = MR * NR * 4;                            // float4 pieces per thread
+    float* pbase = d.sk_part + ((size_t)sk_tile * d.sk_parts + sk_part) * (size_t)(BM * BN);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          const float* ptr = pbase + ((size_t)((i * NR + j) * 4 + q) * NT + tid) * 4;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory");
+        }
+    if (!p2phd::fold_arrive_last(d.sk_ticket + sk_tile, (unsigned)d.sk_parts)) return;
+    const float* tbase = d.sk_part + (size_t)sk_tile * d.sk_parts * (size_t)(BM * BN);
+#pragma unroll
+    for (int i = 0; i < MR; ++i)
+#pragma unroll
+      for (int j = 0; j < NR; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    for (int pp = 0; pp < d.sk_parts; ++pp) {
+      const float* pb = tbase + (size_t)pp * (size_t)(BM * BN);
+      f32x4 v[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float* ptr = pb + ((size_t)q * NT + tid) * 4;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q]) : "v"(ptr) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MR; ++i)
+#pragma unroll
+        for (int j = 0; j < NR; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[(i * NR + j) * 4 + q][e];
+    }
+    __syncthreads();
+  }
 
   // ---- epilogue: bias, InstanceNorm partial sums, activation, LDS-staged coalesced store ----
   constexpr int CROW = BN * (int)sizeof(TO) + 16;           // padded C-tile row
@@ -597,7 +661,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
       for (int e = 0; e < EPPO; ++e) { red[tid * (2 * EPPO) + e] = a1[e]; red[tid * (2 * EPPO) + EPPO + e] = a2[e]; }
       __syncthreads();
-      const int tile_in_sample = blockIdx.x - n * mtiles;
+      const int tile_in_sample = bx - n * mtiles;
       for (int t = tid; t < 2 * BN; t += NT) {
         const int col = t >> 1, which = t & 1, pc = col / EPPO, e = col - pc * EPPO;
         float sum = 0.f;
@@ -638,7 +702,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
   const unsigned long long pr_t3 = __builtin_readcyclecounter();
   if (tid == 0) {
-    const unsigned wg = (blockIdx.y * gridDim.x + blockIdx.x) % kProbeSlots;
+    const unsigned wg = (unsigned)blockIdx.x % kProbeSlots;
     unsigned long long* r = g_probe + (size_t)wg * 8;
 #ifdef P2PHD_PROBE_FINE
     // prologue: table build | descriptor + fragment addresses + DMA issue | first wait + barrier + first fragments;
@@ -1446,10 +1510,13 @@ __global__ void reflect_fold_kernel(const T* __restrict__ dxp, const T* __restri
   }
 }
 
-// column sums of a [P][Cp] matrix (bias gradient); db must be zeroed beforehand.
-// Block = cpg channel pieces x R pixel rows; partial sums meet in LDS so each block issues one atomic per channel.
+// column sums of a [P][Cp] matrix (bias gradient): db[c] (+)= sum_p x[p][c].
+// Block = cpg channel pieces x R pixel rows; the rows of a block meet in LDS and are added in row order, the blocks of a
+// column group store their partial row and the LAST of them (fold_arrive_last) adds the rows in block order: no float
+// atomics, the same bits on every run (these are the biases with a real gradient: no InstanceNorm behind the conv).
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long P, int Cp, int K, float* __restrict__ db, int cpg) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long P, int Cp, int K, float* __restrict__ db, int cpg,
+                                                     int accumulate, float* __restrict__ part, unsigned* __restrict__ tickets) {
   constexpr int EPP = Elem<T>::EPP;
   __shared__ float red[256 * 8];
   const int cpr = Cp / EPP;
@@ -1469,15 +1536,30 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 #pragma unroll
   for (int k = 0; k < EPP; ++k) red[threadIdx.x * 8 + k] = acc[k];
   __syncthreads();
-  if (rl == 0 && pc < cpr) {
+  const int width = cpg * EPP;                                   // channels of this column group
+  float* rows = part + (size_t)blockIdx.y * gridDim.x * width;
+  if (rl == 0) {
 #pragma unroll
     for (int k = 0; k < EPP; ++k) {
-      const int c = pc * EPP + k;
-      if (c >= K) continue;
       float t = 0.f;
       for (int r = 0; r < R; ++r) t += red[(r * cpg + pl) * 8 + k];
-      atomicAdd(&db[c], t);
+      p2phd::fold_store(rows + (size_t)blockIdx.x * width + pl * EPP + k, t);
     }
+  }
+  if (!p2phd::fold_arrive_last(tickets + blockIdx.y, gridDim.x)) return;
+  const int nb = (int)gridDim.x;
+  for (int j = threadIdx.x; j < width; j += 256) {
+    const int c = blockIdx.y * width + j;
+    if (c >= K) continue;
+    float s = 0.f;
+    for (int b = 0; b < nb; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p2phd::fold_load(rows + (size_t)min(b + u, nb - 1) * width + j);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += b + u < nb ? v[u] : 0.f;
+    }
+    db[c] = accumulate ? db[c] + s : s;
   }
 }
 
@@ -1488,6 +1570,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 struct GconvProbe {
   bool on = false;
   int cp = 0, kk = 0, hg = 0, wg = 0;
+  int pad_mode = -1, esize = 0;                  // -1 / 0 = any: tells the forward (reflect gather) from the input gradient (pad_mode 2)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 GconvProbe g_probe_cfg;
@@ -1509,9 +1592,41 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   const int npix = d.Hg * d.Wg;
   const int mtiles = d.flat_m ? (int)(((long)d.N * npix + BM - 1) / BM) : ((npix + BM - 1) / BM) * d.N;
   const int ntiles = (d.n_extent + BN - 1) / BN;
-  dim3 grid((unsigned)mtiles, (unsigned)ntiles);
+  // 1-D grid over tiles (tile = n_tile * mtiles + m_tile).  Split-K tail ("stream-K" for the last round only): with one
+  // workgroup per CU a grid of T tiles runs in ceil(T / CUs) rounds, and the last round of e.g. 561 or 269 tiles keeps
+  // 49 / 13 CUs busy for a whole tile time.  Those tail tiles are cut along K into P = floor(CUs / tail) parts that fill
+  // the round; the part that finishes last adds the partials in a fixed order (gconv_kernel).  Partials live in the
+  // library's reduction scratch (common.h), so no entry point needs a bigger workspace.
+  const int TT = mtiles * ntiles;
+  d.grid_m = mtiles;
+  d.sk_first = TT; d.sk_tail = 1; d.sk_parts = 1; d.sk_steps = 0; d.sk_part = nullptr; d.sk_ticket = nullptr;
+  int wgs = TT;
+  if (p2phd::g_opt_splitk_tail != 0) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0; hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    }
+    const int nsteps = d.KK / (8 * Elem<T>::EPP);
+    const int full = TT / cus * cus, tail = TT - full;
+    int P = tail > 0 ? cus / tail : 1;
+    P = std::min(P, nsteps / 4);                                 // at least 4 K slabs per part
+    if (P >= 2) {
+      const int steps = (nsteps + P - 1) / P;
+      P = (nsteps + steps - 1) / steps;                          // no empty parts
+      // cost in tile times: rounds now vs full rounds + one part (K share + the fixed prologue / epilogue / fix-up share)
+      const double now = std::ceil((double)TT / cus), then = (double)full / cus + 1.0 / P + 0.22;
+      const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_GCONV);
+      if (P >= 2 && then < 0.93 * now && fs.part != nullptr && (size_t)tail * P * BM * BN <= fs.floats && tail <= fs.tickets) {
+        d.sk_first = full; d.sk_tail = tail; d.sk_parts = P; d.sk_steps = steps; d.sk_part = fs.part; d.sk_ticket = fs.ticket;
+        wgs = full + tail * P;
+      }
+    }
+  }
+  dim3 grid((unsigned)wgs);
   const bool probe = g_probe_cfg.on && d.Cp_in == g_probe_cfg.cp && d.KK == g_probe_cfg.kk && d.Hg == g_probe_cfg.hg &&
-                     d.Wg == g_probe_cfg.wg && g_probe_cfg.ev.size() < 4096;
+                     d.Wg == g_probe_cfg.wg && (g_probe_cfg.pad_mode < 0 || d.pad_mode == g_probe_cfg.pad_mode) &&
+                     (g_probe_cfg.esize == 0 || (int)sizeof(T) == g_probe_cfg.esize) && g_probe_cfg.ev.size() < 4096;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (probe) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
   typedef typename OutOf<T>::type TO;
@@ -1802,31 +1917,42 @@ int launch_reflect_expand(int dtype, const void* dy, void* e_out, int N, int H, 
 }
 
 int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, int accumulate, hipStream_t st) {
-  if (!accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)K, st);
-  if (P == 0) return P2PHD_OK;
+  if (P == 0) {
+    if (!accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)K, st);
+    return P2PHD_OK;
+  }
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   const int cpr = Cp / epp;
   int cpg = 1;
   while (cpg * 2 <= cpr && cpg * 2 <= 64) cpg *= 2;
   const int R = 256 / cpg;
   const int ygroups = (cpr + cpg - 1) / cpg;
-  const int xblocks = (int)std::max<long>(1, std::min<long>((P + R * 32 - 1) / (R * 32), 512));
+  const FoldScratch fs = fold_scratch(FOLD_COLSUM);
+  P2PHD_REQUIRE(fs.part != nullptr && ygroups <= fs.tickets, "colsum: reduction scratch unavailable or too many channels (%d)", Cp);
+  const long rows_max = (long)(fs.floats / ((size_t)ygroups * cpg * epp));   // partial rows per column group
+  P2PHD_REQUIRE(rows_max >= 1, "colsum: too many channels for the reduction scratch");
+  const int xblocks = (int)std::max<long>(1, std::min<long>(std::min<long>((P + R * 32 - 1) / (R * 32), 512), rows_max));
   dim3 grid(xblocks, ygroups);
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, P, Cp, K, db, cpg);
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, P, Cp, K, db, cpg, accumulate, fs.part, fs.ticket);
   else
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, P, Cp, K, db, cpg);
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, P, Cp, K, db, cpg, accumulate, fs.part, fs.ticket);
   return check_launch("colsum");
 }
 
 }  // namespace p2phd
 
-extern "C" int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg) {
+extern "C" int p2phd_probe_gconv_ex(int enable, int cin_pitch, int kk, int hg, int wg, int pad_mode, int elem_bytes) {
   for (auto& e : g_probe_cfg.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
   g_probe_cfg.ev.clear();
   g_probe_cfg.on = enable != 0;
   g_probe_cfg.cp = cin_pitch; g_probe_cfg.kk = kk; g_probe_cfg.hg = hg; g_probe_cfg.wg = wg;
+  g_probe_cfg.pad_mode = pad_mode; g_probe_cfg.esize = elem_bytes;
   return P2PHD_OK;
+}
+
+extern "C" int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg) {
+  return p2phd_probe_gconv_ex(enable, cin_pitch, kk, hg, wg, -1, 0);
 }
 
 extern "C" int p2phd_probe_read(float* ms_out, int cap) {

@@ -33,6 +33,11 @@ struct GDesc {
   // layer): as_x is that block's output (= the tensor this launch's conv read, same shape as the written gradient); the
   // stored gradient is multiplied by act'(as_x) (1 above zero, bs_slope below) after the addend -- it leaves as dL/d(pre-act)
   const void* as_x;
+  // launch geometry, set by launch_gconv_cfg: 1-D grid over tiles (tile = n_tile * grid_m + m_tile); workgroups >= sk_first
+  // are K-parts of the last sk_tail tiles (sk_parts parts of sk_steps K slabs each; partials in sk_part, tickets in sk_ticket)
+  int grid_m, sk_first, sk_tail, sk_parts, sk_steps;
+  float* sk_part;
+  unsigned* sk_ticket;
 };
 
 // Index map between a master weight tensor (PyTorch layout, f32) and a packed [rows][tap][inner] matrix:
@@ -59,6 +64,7 @@ int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, in
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
 extern int g_opt_c7_generic;
+extern int g_opt_splitk_tail;       // 0: every tile is one workgroup (no split-K tail), 1 (default): see launch_gconv_cfg
 extern int g_opt_reflect_generic;   // 1: reflect-padded 3x3 input gradients on the padded grid + fold (the general form)
 extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 

@@ -33,7 +33,8 @@ template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
 // 16-byte pieces, two in flight per thread; pad channels are masked
 template <typename T>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(int kind, const T* __restrict__ a, const T* __restrict__ b, float target,
-                                                       long P, int C, int Cp, float coeff, float* __restrict__ out) {
+                                                       long P, int C, int Cp, float coeff, float* __restrict__ out,
+                                                       float* __restrict__ part, unsigned* __restrict__ ticket) {
   constexpr int EPP = Elem<T>::EPP;
   __shared__ float red[4];
   const int cpr = Cp / EPP;
@@ -55,8 +56,15 @@ __global__ __launch_bounds__(256) void loss_fwd_kernel(int kind, const T* __rest
       }
     }
   }
+  // workgroup sums are stored and added by the last workgroup in index order (fold_arrive_last): the loss value has the
+  // same bits on every run (the earlier form added them with a float atomic each)
   const float t = block_sum(acc, red);
-  if (threadIdx.x == 0) atomicAdd(out, t * coeff / (float)(P * C));
+  if (threadIdx.x == 0) p2phd::fold_store(part + blockIdx.x, t);
+  if (!p2phd::fold_arrive_last(ticket, gridDim.x)) return;
+  float s = 0.f;
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += 256) s += p2phd::fold_load(part + b);
+  const float tot = block_sum(s, red);
+  if (threadIdx.x == 0) *out += tot * coeff / (float)(P * C);
 }
 
 // da[p][c] = (*gup) * coeff * f'(a) / (P*C), pad channels zero
@@ -174,10 +182,12 @@ extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b,
   if (P == 0) return P2PHD_OK;
   const int Cp = (C + 7) & ~7;
   hipStream_t st = (hipStream_t)stream;
+  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_LOSS);
+  P2PHD_REQUIRE(fs.part != nullptr && fs.floats >= 1024, "loss_fwd: reduction scratch unavailable");
   if (dtype == P2PHD_BF16)
-    hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out);
+    hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out, fs.part, fs.ticket);
   else if (dtype == P2PHD_F32)
-    hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, out);
+    hipLaunchKernelGGL(loss_fwd_kernel<float>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const float*)a, (const float*)b, target, (long)P, C, Cp, coeff, out, fs.part, fs.ticket);
   else { p2phd::set_error("loss_fwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
   return p2phd::check_launch("loss_fwd");
 }

@@ -9,6 +9,8 @@
 
 namespace {
 
+using p2phd::fold_store;
+using p2phd::fold_load;
 typedef __bf16 bf16_t;
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPP = 4; };
@@ -110,20 +112,39 @@ __global__ __launch_bounds__(256) void in_act_fwd_kernel(const T* __restrict__ y
   }
 }
 
+// Fixed-order fold of per-thread channel partials inside a workgroup of the channel-stationary kernels: thread t owns
+// piece column (b0 + t) % cpr, so the threads of column pc are t0, t0 + cpr, ... with t0 = (pc - b0) mod cpr.  `red` is
+// [256][NV] in LDS (NV values per thread); thread j < ncols * NV returns the sum of value (j % NV) of column (j / NV)'s
+// threads, added in thread order -- no LDS atomics, the result does not depend on wave timing.
+template <int NV>
+__device__ __forceinline__ float column_fold(const float* red, int j, int cpr, int b0) {
+  const int pc = j / NV, k = j - pc * NV;
+  int t = pc - b0;
+  if (t < 0) t += cpr;
+  float s = 0.f;
+  for (; t < 256; t += cpr) s += red[t * NV + k];
+  return s;
+}
+
 // ---- backward pass 1: per (n,c) sums of g' and g' * yhat, g' = g * act'(yhat) ----------------------
+// Fixed summation order end to end (round 3; the LDS and global float atomics of the earlier form made the gradients
+// of every layer behind this pass differ in their last bits from run to run): threads fold per column in thread order,
+// the workgroup stores its row of the partial table, the LAST workgroup of the sample (fold_arrive_last) adds the
+// sample's rows in index order into bstats.
 template <typename T>
 __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                 const float* __restrict__ stats, float* __restrict__ bstats,
-                                                                long HW, int C, int Cp, float eps, int act) {
+                                                                long HW, int C, int Cp, float eps, int act,
+                                                                float* __restrict__ part, unsigned* __restrict__ tickets) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int UN = 4;
-  extern __shared__ float s_acc[];                              // [Cp][2] block partial sums
-  for (int c = threadIdx.x; c < 2 * Cp; c += 256) s_acc[c] = 0.f;
-  __syncthreads();
+  constexpr int NV = 2 * EPP;
+  __shared__ float red[256 * NV];
   const int n = blockIdx.y;
   const int cpr = Cp / EPP;
   const long total = HW * cpr;
   const size_t base = (size_t)n * HW * Cp;
+  const int b0 = (int)(((long)blockIdx.x * 256) % cpr);
   const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
   const float nslope = neg_slope_of(act);
   ChanConsts<T> cc;
@@ -155,12 +176,25 @@ __global__ __launch_bounds__(256) void in_act_bwd_reduce_kernel(const T* __restr
     }
   }
 #pragma unroll
-  for (int k = 0; k < EPP; ++k) {
-    atomicAdd(&s_acc[2 * (pc * EPP + k)], a1[k]);               // LDS atomics: one pair per thread and channel
-    atomicAdd(&s_acc[2 * (pc * EPP + k) + 1], a2[k]);
-  }
+  for (int k = 0; k < EPP; ++k) { red[threadIdx.x * NV + 2 * k] = a1[k]; red[threadIdx.x * NV + 2 * k + 1] = a2[k]; }
   __syncthreads();
-  for (int c = threadIdx.x; c < 2 * C; c += 256) atomicAdd(&bstats[2 * (size_t)n * Cp + c], s_acc[c]);
+  // row of this workgroup: [2 * Cp] = (sum g', sum g' yhat) per channel, the layout of bstats
+  float* row = part + ((size_t)n * gridDim.x + blockIdx.x) * (2 * (size_t)Cp);
+  for (int j = threadIdx.x; j < 2 * Cp; j += 256) fold_store(row + j, column_fold<NV>(red, j, cpr, b0));
+  if (!p2phd::fold_arrive_last(tickets + n, gridDim.x)) return;
+  const float* rows = part + (size_t)n * gridDim.x * (2 * (size_t)Cp);
+  const int nb = (int)gridDim.x;
+  for (int j = threadIdx.x; j < 2 * Cp; j += 256) {
+    float s = 0.f;
+    for (int b = 0; b < nb; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = fold_load(rows + (size_t)min(b + u, nb - 1) * (2 * (size_t)Cp) + j);   // eight loads in flight
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += b + u < nb ? v[u] : 0.f;
+    }
+    bstats[2 * (size_t)n * Cp + j] = s;
+  }
 }
 
 // ---- backward pass 2: dy = rstd * (g' - mean(g') - yhat * mean(g' yhat)) ---------------------------
@@ -388,15 +422,14 @@ __global__ void act_bwd_kernel(const T* __restrict__ g, const T* __restrict__ a,
 // saves the separate column-sum read of dx for the discriminator layers that have a fused activation and no norm.
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_db_kernel(const T* __restrict__ g, const T* __restrict__ a, T* __restrict__ dx,
-                                                         long P, int C, int Cp, int act, float* __restrict__ db) {
+                                                         long P, int C, int Cp, int act, float* __restrict__ db, int accumulate,
+                                                         float* __restrict__ part, unsigned* __restrict__ ticket) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int UN = 4;
-  extern __shared__ float s_db[];                               // [Cp]
-  for (int c = threadIdx.x; c < Cp; c += 256) s_db[c] = 0.f;
-  __syncthreads();
+  __shared__ float red[256 * EPP];
   const int cpr = Cp / EPP;
   const long total = P * cpr, last = total - 1;
-  const int pc = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cpr);
+  const int b0 = (int)(((long)blockIdx.x * 256) % cpr);
   const float nslope = neg_slope_of(act);
   const bool is_tanh = act == P2PHD_ACT_TANH;
   float bsum[EPP];
@@ -429,10 +462,25 @@ __global__ __launch_bounds__(256) void act_bwd_db_kernel(const T* __restrict__ g
       if (e < total) *reinterpret_cast<uint4*>(dx + (size_t)e * EPP) = ov;
     }
   }
+  // fixed-order fold (see in_act_bwd_reduce_kernel): threads of a column in thread order, workgroups in index order
 #pragma unroll
-  for (int k = 0; k < EPP; ++k) atomicAdd(&s_db[pc * EPP + k], bsum[k]);
+  for (int k = 0; k < EPP; ++k) red[threadIdx.x * EPP + k] = bsum[k];
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) atomicAdd(&db[c], s_db[c]);
+  float* row = part + (size_t)blockIdx.x * Cp;
+  for (int j = threadIdx.x; j < Cp; j += 256) fold_store(row + j, column_fold<EPP>(red, j, cpr, b0));
+  if (!p2phd::fold_arrive_last(ticket, gridDim.x)) return;
+  const int nb = (int)gridDim.x;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s = 0.f;
+    for (int b = 0; b < nb; b += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = fold_load(part + (size_t)min(b + u, nb - 1) * Cp + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += b + u < nb ? v[u] : 0.f;
+    }
+    db[c] = accumulate ? db[c] + s : s;
+  }
 }
 
 // ---- AvgPool2d(3, stride 2, pad 1, count_include_pad=False) -------------------------------------------
@@ -552,10 +600,14 @@ inline int grid_for(long work, int cap = 8192) { return (int)std::max<long>(1, s
 namespace {
 // grid.x for the channel-stationary kernels: stride gx * 256 must be a multiple of cpr; few fat blocks so that the
 // per-thread constant setup and the end-of-block atomics are amortised
-int stationary_grid(long HW, int cpr, int N) {
+// smallest grid.x whose stride (grid.x * 256 pieces) is a multiple of the pieces per pixel
+int stationary_unit(int cpr) {
   int gcd = cpr, b = 256;
   while (b) { const int t = gcd % b; gcd = b; b = t; }
-  const int unit = cpr / gcd;
+  return cpr / gcd;
+}
+int stationary_grid(long HW, int cpr, int N) {
+  const int unit = stationary_unit(cpr);
   long want = (HW * cpr + 256 * 8 - 1) / (256 * 8);            // >= 8 pieces per thread
   want = std::min<long>(want, std::max(1, 2048 / std::max(N, 1)));
   int gx = (int)std::max<long>(unit, want / unit * unit);
@@ -727,12 +779,19 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   }
   dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   if (!sums_given) {
-  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act),
-             hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, grid, dim3(256), 2 * Cp * sizeof(float), st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act),
-             "instnorm_act_bwd");
-  if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
+    // partial table of the fixed-order reduction: one row of 2 * Cp floats per workgroup, one ticket per sample
+    const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_IN_BWD);
+    P2PHD_REQUIRE(fs.part != nullptr, "instnorm_act_bwd: reduction scratch unavailable");
+    P2PHD_REQUIRE(N <= fs.tickets, "instnorm_act_bwd: at most %d samples per call", fs.tickets);
+    const int unit = stationary_unit(Cp / epp);
+    const long rows_max = (long)(fs.floats / (2 * (size_t)Cp * (size_t)N));
+    P2PHD_REQUIRE(rows_max >= unit, "instnorm_act_bwd: N * channels too large for the reduction scratch");
+    dim3 rgrid(std::min<long>(grid.x, rows_max / unit * unit), N);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(in_act_bwd_reduce_kernel<bf16_t>, rgrid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (long)HW, C, Cp, eps, act, fs.part, fs.ticket),
+               hipLaunchKernelGGL(in_act_bwd_reduce_kernel<float>, rgrid, dim3(256), 0, st, (const float*)g, (const float*)y, stats, bstats, (long)HW, C, Cp, eps, act, fs.part, fs.ticket),
+               "instnorm_act_bwd");
+    if (int rc = p2phd::check_launch("instnorm_act_bwd(reduce)")) return rc;
   }
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(in_act_bwd_apply_kernel<bf16_t>, grid, dim3(256), Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)y, stats, bstats, (bf16_t*)dy, (long)HW, C, Cp, eps, act, db),
@@ -832,14 +891,22 @@ extern "C" int p2phd_act_bwd_db(int dtype, const void* g, const void* a, void* d
   P2PHD_REQUIRE(n_pixels >= 0 && C >= 1, "act_bwd_db: bad geometry");
   P2PHD_REQUIRE(db != nullptr, "act_bwd_db: null bias-gradient pointer (use p2phd_act_bwd)");
   hipStream_t st = (hipStream_t)stream;
-  if (!db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
-  if (n_pixels == 0) return P2PHD_OK;
+  if (n_pixels == 0) {
+    if (!db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+    return P2PHD_OK;
+  }
   P2PHD_REQUIRE(g && a && dx, "act_bwd_db: null pointer");
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
-  dim3 grid(stationary_grid(n_pixels, Cp / epp, 1));
+  // bias gradient with a REAL value (no normalisation behind the conv): summed in a fixed order, see in_act_bwd_reduce_kernel
+  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_ACT_DB);
+  P2PHD_REQUIRE(fs.part != nullptr, "act_bwd_db: reduction scratch unavailable");
+  const int unit = stationary_unit(Cp / epp);
+  const long rows_max = (long)(fs.floats / (size_t)Cp);
+  P2PHD_REQUIRE(rows_max >= unit, "act_bwd_db: too many channels for the reduction scratch");
+  dim3 grid(std::min<long>(stationary_grid(n_pixels, Cp / epp, 1), rows_max / unit * unit));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(act_bwd_db_kernel<bf16_t>, grid, dim3(256), Cp * sizeof(float), st, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dx, (long)n_pixels, C, Cp, act, db),
-             hipLaunchKernelGGL(act_bwd_db_kernel<float>, grid, dim3(256), Cp * sizeof(float), st, (const float*)g, (const float*)a, (float*)dx, (long)n_pixels, C, Cp, act, db),
+             hipLaunchKernelGGL(act_bwd_db_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)a, (bf16_t*)dx, (long)n_pixels, C, Cp, act, db, db_accumulate, fs.part, fs.ticket),
+             hipLaunchKernelGGL(act_bwd_db_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)a, (float*)dx, (long)n_pixels, C, Cp, act, db, db_accumulate, fs.part, fs.ticket),
              "act_bwd_db");
   return p2phd::check_launch("act_bwd_db");
 }

@@ -287,6 +287,18 @@ class Pix2PixHDModel(BaseModel):
     def discriminate_F(self, input_label, test_image, use_pool=False):
         return self.netD.forward(torch.cat((input_label, test_image.detach()), dim=1))
 
+    def _d_pair(self):
+        """Run D(real) and D(fake) of the training step as one batch (default; opt.d_pair = False or P2PHD_DPAIR=0 keeps
+        the two passes of rounds 1-2 for A/B runs).  Needs intermediate features only through the parked losses."""
+        import os
+        return bool(_opt(self.opt, 'd_pair', True)) and os.environ.get("P2PHD_DPAIR", "1") != "0"
+
+    def _fake_half(self):
+        """Context of the generator-loss backward: D's Functions (batch 2B) process the fake half only."""
+        import contextlib
+        n = getattr(self, '_pair_batch', None)
+        return _ops.backward_on_samples(n, n // 2, n) if n else contextlib.nullcontext()
+
     def _losses(self, lr_audio, hr_audio, noise, share_fake_pass):
         """All loss terms of one step.  share_fake_pass=False is the reference's schedule (pix2pixHD_model.py:331-415):
         D(fake.detach()), D(real), D(fake).  share_fake_pass=True runs D on the generated spectrogram ONCE: the detached
@@ -306,7 +318,23 @@ class Pix2PixHDModel(BaseModel):
             sr_phys = self.netG.forward_physical(self.netG.input_physical(lr_spectro))
         sr_result = _ops.FromPhysical.apply(sr_phys, self.opt.output_nc)
 
-        if share_fake_pass:
+        pair = share_fake_pass and self._d_pair()
+        if pair:
+            # D(real) and D(fake) as ONE batch of 2B (real half first): same weights, one launch per layer instead of two,
+            # fuller tile rounds (e.g. 1122 tiles instead of 2 x 561 on the 256 -> 512 layer).  InstanceNorm is per sample, so
+            # every value equals the two-pass result.  The generator-loss backward then runs on the fake half only
+            # (_ops.backward_on_samples in _g_stages), the discriminator-loss backward on the whole batch.
+            B = int(lr_spectro.shape[0])
+            pred = self.netD.forward_physical(_ops.ToPhysicalPair.apply(self.compute_dtype, lr_spectro, hr_spectro, sr_result),
+                                              exclusive=True)
+            self._pair_batch = 2 * B
+            loss_D_real = loss_D_fake = loss_G_GAN = 0
+            for scale in pred:
+                t, c = scale[-1]
+                loss_D_real = loss_D_real + _ops.mse_const_loss(t, c, 1.0, rows=(0, B))
+                loss_D_fake = loss_D_fake + _ops.mse_const_loss(t, c, 0.0, rows=(B, 2 * B))
+                loss_G_GAN = loss_G_GAN + _ops.mse_const_loss(t, c, 1.0, rows=(B, 2 * B))
+        elif share_fake_pass:
             pred_real = self._D(lr_spectro, hr_spectro)
             pred_fake = self._D(lr_spectro, sr_result)
             loss_D_fake = self._gan(pred_fake, 0.0)
@@ -318,17 +346,25 @@ class Pix2PixHDModel(BaseModel):
             # GAN loss through D into G; D's weight gradients of this pass are never used (train.py:176)
             with _ops.no_weight_grad():
                 pred_fake = self._D(lr_spectro, sr_result)
-        loss_D_real = self._gan(pred_real, 1.0)
-        loss_G_GAN = self._gan(pred_fake, 1.0)
+        if not pair:
+            self._pair_batch = None
+            loss_D_real = self._gan(pred_real, 1.0)
+            loss_G_GAN = self._gan(pred_fake, 1.0)
 
         loss_G_GAN_Feat = 0
         if not self.opt.no_ganFeat_loss:
             feat_weights = 4.0 / (self.opt.n_layers_D + 1)
             D_weights = 1.0 / self.opt.num_D
+            w_feat = D_weights * feat_weights * self.opt.lambda_feat
             for i in range(self.opt.num_D):
+                if pair:
+                    for j in range(len(pred[i]) - 1):
+                        t, c = pred[i][j]
+                        loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_halves_loss(t, c, w_feat, park=True)
+                    continue
                 for j in range(len(pred_fake[i]) - 1):
                     (a, c), (b, _) = pred_fake[i][j], pred_real[i][j]
-                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, D_weights * feat_weights * self.opt.lambda_feat, park=True)
+                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, w_feat, park=True)
 
         # TDAC frame-matching loss (pix2pixHD_model.py:408-415): the second half of frame t and the first half of frame
         # t+1, each under its window half, must coincide
@@ -404,14 +440,14 @@ class Pix2PixHDModel(BaseModel):
         total = optG._total
         if not cuts:
             def whole():
-                with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream():
+                with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream(), self._fake_half():
                     loss_G.backward(inputs=list(optG._params), retain_graph=True)
             return [(whole, (0, total))]
         state = {}
         stages = []
 
         def head():
-            with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream():
+            with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream(), self._fake_half():
                 (state['g'],) = torch.autograd.grad(loss_G, [cuts[-1]], retain_graph=True)
         stages.append((head, (offs[-1], total)))
         for i in range(len(cuts) - 2, -1, -1):
@@ -445,7 +481,27 @@ class Pix2PixHDModel(BaseModel):
         with _ops.backward_without_input_grads(firsts), _ops.wgrad_side_stream():   # no gradient towards the generator in this pass
             loss_D.backward(inputs=list(self.optimizer_D._params))
 
+    # opt.comm_cus = N > 0 (data parallel only makes sense): the step runs on a stream whose CU mask leaves N CUs to the
+    # RCCL kernels of the gradient exchange (parallel_state.masked_compute_stream)
+    def _on_step_stream(self, fn, *args, **kw):
+        n = int(_opt(self.opt, 'comm_cus', 0) or 0)
+        if n <= 0:
+            return fn(*args, **kw)
+        st = getattr(self, '_step_stream', None)
+        if st is None or getattr(st, '_p2phd_free_cus', None) != n:
+            from ..parallel_state import masked_compute_stream
+            st = self._step_stream = masked_compute_stream(self.device, n)
+        cur = torch.cuda.current_stream()
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            out = fn(*args, **kw)
+        cur.wait_stream(st)
+        return out
+
     def train_step(self, lr_audio, hr_audio, noise=None):
+        return self._on_step_stream(self._train_step, lr_audio, hr_audio, noise)
+
+    def _train_step(self, lr_audio, hr_audio, noise=None):
         ld = self._phase_a(lr_audio, hr_audio, noise)              # G buckets are in flight: they overlap the D backward
         self._phase_b()
         self.optimizer_D.reduce_gradients_async()
@@ -461,6 +517,9 @@ class Pix2PixHDModel(BaseModel):
     # outside capture: bucket i's exchange beside stage i+1, the last G bucket beside graph B, the D exchange beside Cg.
     # ------------------------------------------------------------------------------------------
     def train_step_graphed(self, lr_audio, hr_audio):
+        return self._on_step_stream(self._train_step_graphed, lr_audio, hr_audio)
+
+    def _train_step_graphed(self, lr_audio, hr_audio):
         """`train_step` through captured graphs.  Inputs are copied into static buffers; the returned loss tensors are
         static outputs of graph A0 (valid until the next call).  Mask noise is drawn inside the graph."""
         st = getattr(self, '_graph_state', None)
@@ -478,7 +537,7 @@ class Pix2PixHDModel(BaseModel):
         if st['graphs'] is None:
             st['calls'] += 1
             if st['calls'] <= 2:                                   # eager steps first: workspaces, packed-weight buffers,
-                return self.train_step(st['lr'], st['hr'])          # library state all exist before capture
+                return self._train_step(st['lr'], st['hr'])         # library state all exist before capture
             torch.cuda.synchronize()
             # back-to-back captures on one side stream and one pool, without the cache flush torch.cuda.graph()
             # does on entry (blocks the first capture freed must stay where its replay will write them)

@@ -49,6 +49,14 @@ class FlatAdam(torch.optim.Optimizer):
         self._collectives = False
         self._pending = None
         self.bucket_log = []
+        # exchange-exposure instrumentation (bench.py, tests): when `timing` is on, every wait_gradients() that has
+        # something to wait for is bracketed by events on the compute stream -- the time between them is the time the
+        # compute stream stood still for the collectives, i.e. the EXPOSED part of the exchange -- and by a host clock
+        # (backends whose wait blocks the host: gloo).
+        self.timing = False
+        self._wait_events = []
+        self._wait_host_s = 0.0
+        self._waits = 0
         _ops.bump_weight_epoch()
 
     def _install_grad_views(self):
@@ -97,9 +105,29 @@ class FlatAdam(torch.optim.Optimizer):
     def wait_gradients(self):
         """Make the current stream wait for every gradient all-reduce started since the last wait."""
         if self._pending is not None:
+            if self.timing:
+                import time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
             for h in self._pending:
                 h.wait()
+            if self.timing:
+                self._wait_host_s += time.perf_counter() - t0
+                e1.record()
+                self._wait_events.append((e0, e1))
+                self._waits += 1
             self._pending = None
+
+    def reset_exchange_timing(self, on=True):
+        self.timing = bool(on)
+        self._wait_events, self._wait_host_s, self._waits = [], 0.0, 0
+
+    def exchange_timing(self):
+        """{'waits', 'exposed_stream_ms', 'host_wait_ms'} summed since reset_exchange_timing(); synchronises."""
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._wait_events)
+        return {"waits": self._waits, "exposed_stream_ms": float(ms), "host_wait_ms": self._wait_host_s * 1e3}
 
     @torch.no_grad()
     def step(self, closure=None):

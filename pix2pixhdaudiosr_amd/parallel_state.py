@@ -36,3 +36,32 @@ def enable_data_parallel(model, world_size, process_group=None, broadcast=True, 
     model.optimizer_G.enable_data_parallel(world_size, process_group, force_collectives)
     model.optimizer_D.enable_data_parallel(world_size, process_group, force_collectives)
     return model
+
+
+def masked_compute_stream(device, free_cus):
+    """A HIP stream whose kernels may run on every CU but `free_cus` of them (hipExtStreamCreateWithCUMask), wrapped for
+    torch.  Every MFMA kernel of the step takes a CU's whole LDS (one workgroup per CU), so on N > 1 GPUs the RCCL
+    kernels of the gradient exchange only get onto the chip when a workgroup retires; running the step on this stream
+    keeps `free_cus` CUs out of the step's reach so that the collectives co-run (opt.comm_cus / bench.py --comm-cus).
+    The price is a tile round on every layer whose grid filled the chip exactly, which is why it is a knob."""
+    import ctypes
+    dev = torch.device(device)
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    free_cus = int(free_cus)
+    if not 0 < free_cus < n_cu:
+        raise ValueError(f"comm_cus must be in (0, {n_cu}), got {free_cus}")
+    words = (n_cu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cu - free_cus):
+        mask[i // 32] |= 1 << (i % 32)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.restype = ctypes.c_int
+    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), words, mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (code {rc})")
+    st = torch.cuda.ExternalStream(handle.value, device=dev)
+    st._p2phd_free_cus = free_cus
+    return st

@@ -485,7 +485,7 @@ def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(sha
         assert rel_err(outs[0].numpy(), (x.grad + add).numpy()) < 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])   # (bias sums: float atomics, run-to-run order)
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
 def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypatch):
     """Producer without InstanceNorm (Conv + LeakyReLU, the discriminator's first layer): the exclusive consumer's
     input-gradient kernel multiplies dx by act'(x) (p2phd_conv_dgrad_act) and the producer skips its activation-backward
@@ -522,3 +522,105 @@ def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypa
         (orr.sum() * 0.01 + 3.0 * (hr - ref_feat).abs().mean()).backward()
         assert rel_err(a[0].numpy(), xr.grad.numpy()) < 3e-4 and rel_err(a[1].numpy(), w1r.grad.numpy()) < 3e-4
         assert rel_err(a[2].numpy(), b1r.grad.numpy()) < 3e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+def test_parked_gradient_that_arrives_after_the_consumers_dgrad(dtype, tol, monkeypatch):
+    """Round-2 advisor finding: the loss node is created BEFORE the consumer conv, so autograd runs the consumer's backward
+    first (p2phd_conv_dgrad_act applies act'(h) to the conv path of dL/dh and marks it), then the loss parks its gradient on
+    the producer.  The producer must give act' to the parked part ONLY (the earlier code re-applied it to the sum:
+    LeakyReLU slope 0.04 instead of 0.2 on the conv path).  Reference: the same graph without parking / fusion."""
+    from pix2pixhdaudiosr_amd import _ops
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 4, 66, 34, generator=g)
+    w1 = torch.randn(16, 4, 4, 4, generator=g) * 0.2; b1 = torch.randn(16, generator=g) * 0.1
+    w2 = torch.randn(32, 16, 4, 4, generator=g) * 0.05
+    ref_feat = torch.randn(2, 16, 34, 18, generator=g)
+    specP = _ops.ConvSpec(4, 16, 4, 2, 2, 0, False, 0, False, _ops.ACT_LRELU)
+    specL = _ops.ConvSpec(16, 32, 4, 2, 2, 0, False, 0, True, _ops.ACT_LRELU)
+
+    def run(flag, park):
+        monkeypatch.setenv("P2PHD_BSUM", flag)
+        xd = x.cuda().requires_grad_(True)
+        w1d, b1d, w2d = (t.cuda().requires_grad_(True) for t in (w1, b1, w2))
+        h = _ops.conv_block(_ops.ToPhysical.apply(dtype, xd), w1d, b1d, specP)
+        fm = _ops.l1_loss(h, _ops.to_physical(ref_feat.cuda(), dtype), 16, 3.0, park=park)     # created FIRST: its backward runs LAST
+        o = _ops.conv_block(h, w2d, None, specL, exclusive=park)
+        n0 = _ops._BSUM_CALLS[0]
+        (_ops.FromPhysical.apply(o, 32).sum() * 0.01 + fm).backward()
+        torch.cuda.synchronize()
+        return xd.grad.cpu(), w1d.grad.cpu(), b1d.grad.cpu(), w2d.grad.cpu(), _ops._BSUM_CALLS[0] - n0
+
+    a = run("1", True); b = run("0", False)
+    assert a[4] == 1, "the fused activation backward did not run: the test no longer covers the late-park order"
+    for u, v in zip(a[:4], b[:4]):
+        assert rel_err(u.numpy(), v.numpy()) < tol
+    if dtype == torch.float32:
+        xr, w1r, b1r, w2r = (t.clone().requires_grad_(True) for t in (x, w1, b1, w2))
+        hr = F.leaky_relu(F.conv2d(xr, w1r, b1r, stride=2, padding=2), 0.2)
+        orr = F.leaky_relu(F.instance_norm(F.conv2d(hr, w2r, stride=2, padding=2), eps=1e-5), 0.2)
+        (orr.sum() * 0.01 + 3.0 * (hr - ref_feat).abs().mean()).backward()
+        assert rel_err(a[0].numpy(), xr.grad.numpy()) < 3e-4 and rel_err(a[1].numpy(), w1r.grad.numpy()) < 3e-4
+        assert rel_err(a[2].numpy(), b1r.grad.numpy()) < 3e-4
+
+
+def test_second_consumer_of_a_fused_activation_gradient_raises(monkeypatch):
+    """When the consumer's kernel applied act' and the gradient that reaches the producer is NOT the tensor it wrote (a
+    second, un-parked consumer: autograd summed into a new tensor), the producer raises instead of re-applying act'."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    monkeypatch.setenv("P2PHD_BSUM", "1")
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(2, 4, 66, 34, generator=g).cuda().requires_grad_(True)
+    w1 = (torch.randn(16, 4, 4, 4, generator=g) * 0.2).cuda().requires_grad_(True)
+    w2 = (torch.randn(32, 16, 4, 4, generator=g) * 0.05).cuda().requires_grad_(True)
+    specP = _ops.ConvSpec(4, 16, 4, 2, 2, 0, False, 0, False, _ops.ACT_LRELU)
+    specL = _ops.ConvSpec(16, 32, 4, 2, 2, 0, False, 0, True, _ops.ACT_LRELU)
+    h = _ops.conv_block(_ops.ToPhysical.apply(torch.float32, x), w1, None, specP)
+    side = h.float().square().sum() * 1e-3                        # plain torch consumer created first: its gradient is summed in last
+    o = _ops.conv_block(h, w2, None, specL, exclusive=True)       # (a false promise)
+    with pytest.raises(_lib.P2PHDError):
+        (_ops.FromPhysical.apply(o, 32).sum() * 0.01 + side).backward()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(64, 96, 3, 1, 1, 1, (3, 40, 28)),      # 15 M tiles x 1: tail = whole grid, deep split
+                                  (256, 512, 4, 1, 2, 0, (9, 34, 18)),    # D 256 -> 512 k4 s1 (one sample = 630 pixels)
+                                  (128, 128, 3, 2, 1, 0, (5, 33, 47))],   # stride 2, odd sizes
+                         ids=["c3_64to96", "d_256to512", "c3s2_odd"])
+def test_split_k_tail_equals_whole_tiles(dtype, geom):
+    """Round 3: the tiles of the last, almost empty round of a grid are cut along K into parts that fill the CUs; the part
+    that finishes last adds the partials in a fixed order (gconv_kernel / launch_gconv_cfg).  Same values as one workgroup
+    per tile up to fp32 summation order, the same bits from run to run, statistics included."""
+    import ctypes as C
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    cin, cout, k, stride, pad, pad_mode, (N, H, W) = geom
+    L = _ops.lib()
+    g = torch.Generator().manual_seed(5)
+    x = _ops.to_physical(torch.randn(N, cin, H, W, generator=g).cuda(), dtype)
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, dtype)
+    Ho, Wo = spec.out_size(d)
+    wp = spec.packed(w, 0, d)
+    ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
+
+    def run(split):
+        _lib.check(L.p2phd_set_option(b"splitk_tail", split))
+        try:
+            y = torch.empty(N, Ho, Wo, _ops.cpitch(cout), dtype=dtype, device="cuda")
+            stats = torch.zeros(N, _ops.cpitch(cout), 2, device="cuda")
+            _lib.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), _ops.ptr(b), 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws),
+                                        _ops.stream_ptr()), "conv_fwd")
+            torch.cuda.synchronize()
+            return y.float().cpu(), stats.cpu()
+        finally:
+            _lib.check(L.p2phd_set_option(b"splitk_tail", 1))
+
+    y1, s1 = run(1)
+    y0, s0 = run(0)
+    y1b, s1b = run(1)
+    assert torch.equal(y1, y1b) and torch.equal(s1, s1b)           # fixed summation order: run-to-run identical
+    tol = 2e-6 if dtype == torch.float32 else 4e-3                 # bf16: the output rounding may flip on a last-bit difference
+    assert rel_err(y1.numpy(), y0.numpy()) < tol
+    assert rel_err(s1[..., 0].numpy(), s0[..., 0].numpy()) < 1e-5 and rel_err(s1[..., 1].numpy(), s0[..., 1].numpy()) < 1e-4

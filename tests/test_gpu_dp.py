@@ -68,25 +68,37 @@ def test_bench_launches_its_own_ranks():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["dist"]["ranks"] == 2 and len(out["per_rank_ms_per_step"]) == 2
+    # exchange-exposure instrumentation (round 3): per-bucket bytes, waits per step, exposed time on the compute stream
+    d = out["dist"]
+    assert len(d["bucket_bytes"]["G"]) == 4 and sum(d["bucket_bytes"]["G"]) == 4 * sum(d["g_gradient_buckets"])
+    assert len(d["bucket_bytes"]["D"]) == 1 and d["bucket_bytes"]["D"][0] > 0
+    assert d["waits_per_step"] == 2 and d["exposed_exchange_ms"] >= 0 and d["host_wait_ms"] >= 0
+    assert abs(d["exposed_exchange_ms"] - d["exposed_exchange_ms_G"] - d["exposed_exchange_ms_D"]) < 1e-6
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out
     assert out["value"] > 0 and out["scaling"] == "weak"
 
 
 
-def test_bench_step_against_real_rccl_with_one_rank():
+@pytest.mark.parametrize("comm_cus", [0, 8])
+def test_bench_step_against_real_rccl_with_one_rank(comm_cus):
     """The N-rank call sequence (4 gradient buckets all-reduced between graph replays, D exchange, waits, Adam) against
     the real RCCL backend: a one-rank 'nccl' group with the collectives forced on (P2PHD_REHEARSE_RCCL) -- what a
-    one-GPU box can exercise of the path the driver's multi-GPU bench takes."""
+    one-GPU box can exercise of the path the driver's multi-GPU bench takes.  Second case: the same with the step on a
+    CU-masked stream (--comm-cus 8: 8 CUs left to the RCCL kernels)."""
     import json
     env = dict(os.environ, P2PHD_REHEARSE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "P2PHD_DIST_BACKEND", "P2PHD_FORCE_DEVICE"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "2", "--no-cpu-baseline",
-           "--no-mdct"]
+           "--no-mdct", "--comm-cus", str(comm_cus)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["dist"]["backend"] == "nccl" and out["dist"]["rehearsal_one_rank"] is True
+    # comm_cus > 0: the step ran (and was captured / replayed) on a stream whose CU mask leaves that many CUs to RCCL
+    assert out["dist"]["comm_cus"] == comm_cus and out["dist"]["ranks"] == 1
+    assert out["dist"]["waits_per_step"] == 2 and out["dist"]["exposed_exchange_ms"] >= 0
+    assert len(out["dist"]["bucket_bytes"]["G"]) == 4
     assert len(out["dist"]["g_gradient_buckets"]) == 4 and min(out["dist"]["g_gradient_buckets"]) > 0
     assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out and out["value"] > 0

@@ -3,7 +3,10 @@
   * configs[1]: GlobalGenerator ngf 48 / 4 down-samplings / 9 blocks + 2-scale discriminator on a 512x256 spectrogram,
     one sample: the four losses, the generated spectrogram, the gradients of BOTH backward passes (train.py:155-184);
   * configs[2] (opt.txt reading of G3L2_48ngf): LocalEnhancer forward at 512x256;
-  * configs[4]: the 3-scale discriminator against the reference's own outputs (tests/golden/networks_d3.npz)."""
+  * configs[4]: the 3-scale discriminator against the reference's own outputs (tests/golden/networks_d3.npz);
+  * round 3: configs[0] at its real geometry (ngf 32 global, 512x256, B = 2: one whole step incl. codec and Adam against
+    oracle.model.full_step), configs[2]'s LocalEnhancer BACKWARD at 512x256, configs[4]'s full model (n_fft 2048, ngf 64
+    local generator = 730 713 346 parameters, 3-scale D, 1024x512, bf16 + fp8) through one graphed step."""
 import os
 
 import numpy as np
@@ -37,7 +40,8 @@ def test_configs1_network_losses_and_both_backward_passes():
     oo = OM.default_opt(ngf=48, netG="global", n_downsample_global=4, n_blocks_global=9, mask=False)
     pG = OM.N.init_params(OM.netG_spec(oo), seed=1)
     pD = OM.N.init_params(OM.netD_spec(oo), seed=2)
-    assert sum(v.numel() for v in pG.values()) == 102_593_186 or True      # parameter-count KATs live in test_oracle_networks
+    assert sum(v.numel() for v in pG.values()) == 102_627_170              # configs[1]'s generator (bench.py prints the same count)
+    assert sum(v.numel() for v in pD.values()) == 5_531_522                # train_script.sh KAT
     hr, lr, _ = OM.synthetic_batch(1, oo, seed=5)
     w = M4.kbdwin(oo.win_length)
     hr_s, _, _ = OM.to_spectro(hr, oo, w, mask=False)
@@ -58,36 +62,47 @@ def test_configs1_network_losses_and_both_backward_passes():
     got = dict(zip(m.loss_names, losses))
     for k in ("G_GAN", "G_GAN_Feat", "D_real", "D_fake"):
         assert abs(float(got[k]) - L[k]) <= 5e-4 * max(1.0, abs(L[k])), (k, float(got[k]), L[k])
-    # north_star: activations within 1e-4 rel of the reference CPU path.  On THIS input (a dB spectrogram: nearly
-    # constant channels in front of InstanceNorm) the reference's own fp32 path is itself ~5e-5 away from the exact
-    # result, so two fp32 summation orders cannot be expected closer than that to each other: the bound is 1e-4 against
-    # the fp32 CPU path OR no more than 4x as far from the fp64 result as that path is (tools/probe_depth_error.py: the
-    # HIP fp32 MFMA chain sums k-ordered and is 2-3x the blocked CPU sum, layer by layer, on any input).
+    # north_star: activations within 1e-4 rel of the reference CPU path, no alternative (measured 1.1e-5 since the
+    # InstanceNorm statistics are per-wave (sum, M2) partials merged with Chan's update; the fp64 distances are printed
+    # for context only).
     e_sr = rel_err(sr.detach().cpu().numpy(), L["sr"].numpy())
     e_hip64 = rel_err(sr.detach().cpu().numpy(), sr64.numpy())
     e_cpu64 = rel_err(L["sr"].numpy(), sr64.numpy())
     print(f"full-size generator output: HIP vs CPU fp32 {e_sr:.2e}; vs fp64: HIP {e_hip64:.2e}, CPU fp32 {e_cpu64:.2e}")
-    assert e_sr < 1e-4 or e_hip64 < 4 * e_cpu64, (e_sr, e_hip64, e_cpu64)
-    assert e_sr < 5e-4
+    assert e_sr < 1e-4, (e_sr, e_hip64, e_cpu64)
     m.optimizer_G.zero_grad(); (got["G_GAN"] + got["G_GAN_Feat"]).backward(retain_graph=True)
     gG_hip = {k: p.grad.detach().cpu().clone() for k, p in m.netG.named_parameters()}
     m.optimizer_D.zero_grad(); ((got["D_fake"] + got["D_real"]) * 0.5).backward()
     gD_hip = {k: p.grad.detach().cpu().clone() for k, p in m.netD.named_parameters()}
-    # 28 generator layers deep, each InstanceNorm + ReLU: a ReLU whose normalised input is within fp32 rounding of 0
-    # takes the other branch in one of the two implementations, which moves a gradient element by a full term.  Bound:
-    # 2e-3 relative L2 per tensor (measured worst 6e-4), whole-network 5e-4.
+    # Gradients.  Round 2 bounded these at 5e-2 and quoted "measured worst 6e-4"; the round-2 review asked for 2e-3.  Neither
+    # figure survives measurement: on this input the REFERENCE'S OWN fp32 CPU path is 7e-3 .. 1e-2 away from the exact
+    # (fp64) gradient on every generator layer (profiles/r03_reference_fp32_vs_fp64_gradients.txt: the L1 feature-matching
+    # term differentiates sign(fake - real) and every InstanceNorm + ReLU has elements within fp32 rounding of its kink;
+    # one flipped branch moves the gradient by a full term), so two correct fp32 implementations cannot agree better than
+    # that with each other.  The anchor is therefore the exact gradient: per tensor, the HIP path must be no farther from
+    # the fp64 result than 2x the reference's fp32 path is (+1e-4), and within 3e-2 of that path in any case.
+    L64, gG64, gD64 = OM.step_grads({k: v.double() for k, v in pG.items()}, {k: v.double() for k, v in pD.items()},
+                                    lr_s.double(), hr_s.double(), oo)
     nbG, nbD = noise_bias_keys(list(gG)), noise_bias_keys(list(gD))
     report = []
-    for tag, ref, hip, nb in (("G", gG, gG_hip, nbG), ("D", gD, gD_hip, nbD)):
+    for tag, ref, ref64, hip, nb in (("G", gG, gG64, gG_hip, nbG), ("D", gD, gD64, gD_hip, nbD)):
         for k, v in ref.items():
-            if k not in nb:
-                report.append((f"{tag}:{k}", rel_err(hip[k].numpy(), v.numpy()), float(v.norm())))
-    for name, e, nrm in report:
-        print(f"  grad {name:40s} rel err {e:.2e}  |ref| {nrm:.3e}")
+            if k in nb:
+                continue
+            e_hip = rel_err(hip[k].numpy(), ref64[k].numpy())
+            e_cpu = rel_err(v.numpy(), ref64[k].numpy())
+            e_pair = rel_err(hip[k].numpy(), v.numpy())
+            report.append((f"{tag}:{k}", e_hip, e_cpu, e_pair))
+    for name, e_hip, e_cpu, e_pair in report:
+        print(f"  grad {name:40s} vs fp64: HIP {e_hip:.2e}  CPU fp32 {e_cpu:.2e} | HIP vs CPU fp32 {e_pair:.2e}")
     globals()["_LAST_REPORT"] = report
+    for name, e_hip, e_cpu, e_pair in report:
+        assert e_hip <= 2.0 * e_cpu + 1e-4, (name, e_hip, e_cpu)
+        assert e_pair <= 3e-2, (name, e_pair)
+    # biases in front of an InstanceNorm: exact gradient 0, both sides hold rounding noise -- absolute bound only
     for tag, ref, hip, nb in (("G", gG, gG_hip, nbG), ("D", gD, gD_hip, nbD)):
-        for k, v in ref.items():
-            assert_grad_close(f"{tag}:{k}", hip[k].numpy(), v.numpy(), rtol=5e-2, bias_floor=2e-2, noise_biases=nb)
+        for k in nb:
+            assert_grad_close(f"{tag}:{k}", hip[k].numpy(), ref[k].numpy(), rtol=0.0, bias_floor=2e-2, noise_biases=nb)
 
 
 def test_configs2_local_enhancer_forward_full_size():
@@ -199,3 +214,117 @@ def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size():
     assert max(d_err) < 1.5e-1, max(d_err)
     assert min(c for _, c, _ in worst) > 0.8
     assert [e for e, _, n in worst if n == "G:model.38.weight"][0] < 1.5e-1
+
+
+def test_configs0_one_step_at_real_geometry_against_the_oracle():
+    """BASELINE configs[0] ("CPU reference: n_fft 1024 (512x256), ngf 32, 1 global G, 2-scale D, batch 2"): the WHOLE step
+    -- MDCT4 + dB codec + mode2 mask with injected noise, G, D x3, the four losses, both backward passes, both Adam
+    updates (train.py:148-184) -- against oracle.model.full_step on the same audio and weights, fp32."""
+    from oracle import model as OM
+    from oracle import mdct4 as M4
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    from pix2pixhdaudiosr_amd import _ops
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    oo = OM.default_opt(ngf=32, netG="global", n_downsample_global=4, n_blocks_global=9, mask=True)
+    pG = OM.N.init_params(OM.netG_spec(oo), seed=11)
+    pD = OM.N.init_params(OM.netD_spec(oo), seed=12)
+    assert sum(v.numel() for v in pG.values()) == 45_617_730
+    hr, lr, noise = OM.synthetic_batch(2, oo, seed=7)
+    w = M4.kbdwin(oo.win_length)
+    L, pG1, pD1 = OM.full_step(hr, lr, noise, dict(pG), dict(pD), oo, w, {}, {})
+
+    m = create_model(_opt(ngf=32, mask=True))
+    _load_from(m.netG, pG); _load_from(m.netD, pD)
+    _ops.bump_weight_epoch()
+    ld = m.train_step(lr, hr, noise=noise)
+    for k in ("G_GAN", "G_GAN_Feat", "D_real", "D_fake"):
+        assert abs(float(ld[k]) - L[k]) <= 5e-4 * max(1.0, abs(L[k])), (k, float(ld[k]), L[k])
+    # weights after Adam: the first step moves every element by +-lr (sign of its gradient), so an element agrees with the
+    # oracle exactly or is off by 2 lr; elements whose gradient is rounding noise (biases in front of an InstanceNorm, and
+    # the near-zero tail of every tensor) may take either sign.  Bound the share of disagreeing weight elements.
+    for net, ref in ((m.netG, pG1), (m.netD, pD1)):
+        nb = noise_bias_keys(list(ref))
+        for k, p in net.state_dict().items():
+            if k in nb:
+                continue
+            bad = float(((p.detach().cpu() - ref[k]).abs() > 1e-6).float().mean())
+            assert bad < 2e-2, (k, bad)
+
+
+def test_configs2_local_enhancer_backward_full_size():
+    """configs[2] (GEN_VCTK_G3L2_48ngf as opt.txt reads it): forward AND backward of the LocalEnhancer at 512x256, one
+    sample, fp32, against the oracle: input gradient and every parameter gradient for a fixed linear functional of the
+    output (models/networks.py:129-183)."""
+    from oracle import networks as N
+    from pix2pixhdaudiosr_amd.models import networks as PN
+    from pix2pixhdaudiosr_amd import _ops
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    spec = N.local_enhancer_spec(2, 2, 48, 4, 3, 1, 2)
+    p = {k: v.clone().requires_grad_(True) for k, v in N.init_params(spec, seed=3).items()}
+    gen = torch.Generator().manual_seed(10)
+    x = torch.rand(1, 2, 512, 256, generator=gen).requires_grad_(True)
+    c = torch.randn(1, 2, 512, 256, generator=gen)
+    ref = N.local_enhancer_forward(p, x, 4, 3, 1, 2)
+    gref = torch.autograd.grad((ref * c).sum(), [x] + list(p.values()))
+    net = PN.define_G(2, 2, 48, "local", 4, 3, 1, 2, "instance", [], dtype=torch.float32, verbose=False)
+    net.load_state_dict({k: p[k].detach() for k in net.state_dict().keys()})
+    net = net.cuda()
+    _ops.bump_weight_epoch()
+    xd = x.detach().cuda().requires_grad_(True)
+    y = net(xd)
+    assert rel_err(y.detach().cpu().numpy(), ref.detach().numpy()) < 1e-4
+    params = dict(net.named_parameters())
+    ghip = torch.autograd.grad((y * c.cuda()).sum(), [xd] + list(params.values()))
+    # anchor = the exact (fp64) gradient of the same functional, as in the configs[1] test above: a ReLU input within fp32
+    # rounding of 0 takes either branch, so the reference's fp32 path is itself ~5e-3 from the exact input gradient
+    p64 = {k: v.detach().double().requires_grad_(True) for k, v in p.items()}
+    x64 = x.detach().double().requires_grad_(True)
+    g64 = torch.autograd.grad((N.local_enhancer_forward(p64, x64, 4, 3, 1, 2) * c.double()).sum(), [x64] + list(p64.values()))
+    nb = noise_bias_keys(list(params))
+    names = ["input"] + list(params.keys())
+    for name, gh, gr, ge in zip(names, ghip, gref, g64):
+        if name in nb:
+            assert_grad_close(f"L:{name}", gh.cpu().numpy(), gr.numpy(), rtol=0.0, bias_floor=2e-2, noise_biases=nb)
+            continue
+        e_hip, e_cpu = rel_err(gh.cpu().numpy(), ge.numpy()), rel_err(gr.numpy(), ge.numpy())
+        print(f"  grad L:{name:36s} vs fp64: HIP {e_hip:.2e}  CPU fp32 {e_cpu:.2e}")
+        assert e_hip <= 2.0 * e_cpu + 1e-4, (name, e_hip, e_cpu)
+        assert rel_err(gh.cpu().numpy(), gr.numpy()) <= 3e-2, name
+
+
+def test_configs4_full_model_one_graphed_step_bf16_fp8():
+    """configs[4] per GPU: n_fft 2048 (1024x512 spectrograms), ngf 64 LocalEnhancer (the reference's default generator,
+    730 713 346 parameters -- train_script.sh KAT), 3-scale discriminator, bf16 + fp8 forward of the wide convs, batch 2,
+    through the captured-graph step.  No CPU oracle at this size (minutes per step): size-independent properties."""
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    o = _opt(n_fft=2048, hop_length=1024, win_length=2048, ngf=64, netG="local", n_downsample_global=4, n_blocks_global=9,
+             n_local_enhancers=1, n_blocks_local=3, num_D=3, fp16=True, fp8=True, mask=True)
+    m = create_model(o)
+    assert sum(p.numel() for p in m.netG.parameters()) == 730_713_346
+    assert m.fp8_layers > 0
+    T = 511 * 1024
+    gen = torch.Generator().manual_seed(3)
+    hr = (0.1 * torch.randn(2, T, generator=gen)).cuda()
+    lr = (0.1 * torch.randn(2, T, generator=gen)).cuda()
+    # feature structure of the 3-scale D at this geometry (15 features: 3 scales x 5 stages)
+    with torch.no_grad():
+        ls, _, hs, _, _, _, _, _ = m.encode_input(lr, None, hr, None)
+        assert tuple(ls.shape) == (2, 2, 1024, 512)
+        feats = m.netD(torch.cat((ls, hs), dim=1))
+    assert [len(s) for s in feats] == [5, 5, 5]
+    shapes = [tuple(f.shape) for s in feats for f in s]
+    assert shapes[0] == (2, 64, 513, 257) and shapes[4] == (2, 1, 131, 67) and shapes[5] == (2, 64, 257, 129) and shapes[14] == (2, 1, 35, 19), shapes
+    w0 = m.optimizer_G.flat_p.clone()
+    for _ in range(4):                                             # 2 eager steps, capture, one more replay
+        ld = m.train_step_graphed(lr, hr)
+    torch.cuda.synchronize()
+    assert m._graph_state["graphs"] is not None
+    for k in ("G_GAN", "G_GAN_Feat", "D_real", "D_fake"):
+        assert np.isfinite(float(ld[k])) and float(ld[k]) > 0, (k, float(ld[k]))
+    assert torch.isfinite(m.optimizer_G.flat_p).all() and torch.isfinite(m.optimizer_D.flat_p).all()
+    # every parameter tensor received a gradient in the last replay (nonzero in every layer, G and D)
+    for opt_ in (m.optimizer_G, m.optimizer_D):
+        for p_, off in zip(opt_._params, opt_._offs):
+            seg = opt_.flat_g[off:off + p_.numel()]
+            assert torch.isfinite(seg).all() and float(seg.abs().max()) > 0, (tuple(p_.shape), off)
+    assert float((m.optimizer_G.flat_p - w0).abs().max()) > 0
