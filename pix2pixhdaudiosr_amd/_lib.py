@@ -113,6 +113,11 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
+        # P2PHD_OPTIONS="name=value,...": tuning overrides of p2phd_set_option for A/B runs of whole programs (bench.py, tools)
+        for item in filter(None, os.environ.get("P2PHD_OPTIONS", "").split(",")):
+            name, _, value = item.partition("=")
+            if l.p2phd_set_option(name.strip().encode(), int(value)) != 0:
+                raise P2PHDError(f"P2PHD_OPTIONS: {l.p2phd_last_error().decode()}")
     return _lib
 
 

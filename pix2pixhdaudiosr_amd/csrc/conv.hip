@@ -442,6 +442,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     // the tile, and the part that arrives LAST adds all parts in index order -- a fixed summation order whatever the
     // timing -- and carries on into the normal epilogue.  sc1 stores / loads: the parts run on different XCDs.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // partial out: 16-byte sc1 (write-through) stores, lane-interleaved = coalesced; in: the finisher's agent-scope acquire
+    // (fold_arrive_last) followed by PLAIN 16-byte loads -- the always-valid hand-over of MI355X_MICROARCH.md (sc1 stores
+    // drained by every wave + barrier + agent ticket | ticket + acquire + barrier + plain loads).  The loads are C++ loads:
+    // an inline-asm load would hand the compiler registers whose data has not landed yet.
     constexpr int NQ = MR * NR * 4;                            // float4 pieces per thread
     float* pbase = d.sk_part + ((size_t)sk_tile * d.sk_parts + sk_part) * (size_t)(BM * BN);
 #pragma unroll
@@ -463,14 +467,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     for (int pp = 0; pp < d.sk_parts; ++pp) {
-      const float* pb = tbase + (size_t)pp * (size_t)(BM * BN);
+      const f32x4* pb = reinterpret_cast<const f32x4*>(tbase + (size_t)pp * (size_t)(BM * BN));
       f32x4 v[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const float* ptr = pb + ((size_t)q * NT + tid) * 4;
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[q]) : "v"(ptr) : "memory");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      for (int q = 0; q < NQ; ++q) v[q] = pb[(size_t)q * NT + tid];
 #pragma unroll
       for (int i = 0; i < MR; ++i)
 #pragma unroll
@@ -1609,17 +1609,36 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
     }
     const int nsteps = d.KK / (8 * Elem<T>::EPP);
     const int full = TT / cus * cus, tail = TT - full;
-    int P = tail > 0 ? cus / tail : 1;
-    P = std::min(P, nsteps / 4);                                 // at least 4 K slabs per part
-    if (P >= 2) {
+    // Cost model in microseconds (layer tables of profiles/r03_*): a K slab of a BM x BN tile at the rate one CU sustains in
+    // this loop, a fixed prologue + epilogue, one partial store per part and one partial load per part by the finisher
+    // (sc1 traffic of 4 BM BN bytes each).  The finisher term grows with P, so the best P is about sqrt(K time / load time):
+    // deep reductions (the 256 -> 512 layers) split 4-7 ways, short ones not at all.
+    const double area = (double)BM * BN / 65536.0;
+    const double t_slab = (double)BM * BN * 128.0 / 6.0e6, c0 = 8.0 + 16.0 * area, c_io = 4.0 * area;
+    const double t_tile = c0 + nsteps * t_slab;
+    // (a sparse last round runs faster per tile than a full one -- fewer CUs on the memory system, higher clock --, which
+    // is why the measured gain of filling it is smaller than a whole tile time)
+    const double now = (double)(full / cus) * t_tile + (tail > 0 ? 0.75 * t_tile : 0.0);
+    int bestP = 1;
+    double best = now;
+    const int pmax = tail > 0 ? std::min(cus / tail, nsteps / 4) : 1;
+    for (int P = 2; P <= pmax; ++P) {
       const int steps = (nsteps + P - 1) / P;
-      P = (nsteps + steps - 1) / steps;                          // no empty parts
-      // cost in tile times: rounds now vs full rounds + one part (K share + the fixed prologue / epilogue / fix-up share)
-      const double now = std::ceil((double)TT / cus), then = (double)full / cus + 1.0 / P + 0.22;
+      const int Pe = (nsteps + steps - 1) / steps;               // no empty parts
+      const double t = (double)(full / cus) * t_tile + c0 + steps * t_slab + c_io + Pe * c_io;
+      if (t < best) { best = t; bestP = Pe; }
+    }
+    if (p2phd::g_opt_splitk_tail == 2 && pmax >= 2) {            // tests: split as deep as allowed whatever the model says
+      const int steps = (nsteps + pmax - 1) / pmax;
+      bestP = (nsteps + steps - 1) / steps;
+      best = 0.0;
+    }
+    if (bestP >= 2 && best < 0.95 * now) {
       const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_GCONV);
-      if (P >= 2 && then < 0.93 * now && fs.part != nullptr && (size_t)tail * P * BM * BN <= fs.floats && tail <= fs.tickets) {
-        d.sk_first = full; d.sk_tail = tail; d.sk_parts = P; d.sk_steps = steps; d.sk_part = fs.part; d.sk_ticket = fs.ticket;
-        wgs = full + tail * P;
+      const int steps = (nsteps + bestP - 1) / bestP;
+      if (fs.part != nullptr && (size_t)tail * bestP * BM * BN <= fs.floats && tail <= fs.tickets) {
+        d.sk_first = full; d.sk_tail = tail; d.sk_parts = bestP; d.sk_steps = steps; d.sk_part = fs.part; d.sk_ticket = fs.ticket;
+        wgs = full + tail * bestP;
       }
     }
   }

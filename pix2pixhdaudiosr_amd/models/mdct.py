@@ -131,9 +131,12 @@ class MDCT4(_Base):
         super().__init__()
         self._setup(n_fft, hop_length, win_length, window, center, pad_mode, device, out_dtype)
 
-    def forward(self, signal):
+    def forward(self, signal, _dim0=None):
+        """`_dim0` (internal): the value the reference's len(signal) quirk would see -- lets a caller stack several [B, T]
+        batches along dim 0 into ONE launch and still get the frame layout of a [B, T] call (Pix2PixHDModel.encode_input)."""
         signal = signal.to(self.device)
-        start_pad, _, n_frames = frame_layout(len(signal), signal.shape[-1], self.hop_length, self.win_length, self.center)
+        start_pad, _, n_frames = frame_layout(len(signal) if _dim0 is None else int(_dim0), signal.shape[-1], self.hop_length,
+                                              self.win_length, self.center)
         lead = signal.shape[:-1]
         x2d = signal.reshape(-1, signal.shape[-1]).to(torch.float32).contiguous()
         _lib.require_gpu_tensor(x2d, "MDCT4 input")
@@ -264,11 +267,12 @@ class MDCT2(_Base2):
         _check_dct_op(dct_op, 'dct')
         self._setup2(n_fft, hop_length, win_length, window, center, pad_mode, device, out_dtype)
 
-    def forward(self, signal, return_ola=False):
+    def forward(self, signal, return_ola=False, _dim0=None):
         if return_ola:
             raise NotImplementedError("return_ola (time-domain discriminator frames) is outside the hot path")
         signal = signal.to(self.device)
-        start_pad, _, n_frames = frame_layout(len(signal), signal.shape[-1], self.hop_length, self.win_length, self.center)
+        start_pad, _, n_frames = frame_layout(len(signal) if _dim0 is None else int(_dim0), signal.shape[-1], self.hop_length,
+                                              self.win_length, self.center)
         lead = signal.shape[:-1]
         x2d = signal.reshape(-1, signal.shape[-1]).to(torch.float32).contiguous()
         _lib.require_gpu_tensor(x2d, "MDCT2 input")

@@ -284,7 +284,9 @@ def test_configs2_local_enhancer_backward_full_size():
     names = ["input"] + list(params.keys())
     for name, gh, gr, ge in zip(names, ghip, gref, g64):
         if name in nb:
-            assert_grad_close(f"L:{name}", gh.cpu().numpy(), gr.numpy(), rtol=0.0, bias_floor=2e-2, noise_biases=nb)
+            # bias in front of an InstanceNorm: exact gradient 0; both sides hold the rounding noise of a sum over the plane
+            # (here up to 131 072 pixels x 1 .. 768 channels: ~0.2 in norm), which says nothing about either side
+            assert np.isfinite(gh.cpu().numpy()).all() and float(gh.abs().max()) < 1.0, name
             continue
         e_hip, e_cpu = rel_err(gh.cpu().numpy(), ge.numpy()), rel_err(gr.numpy(), ge.numpy())
         print(f"  grad L:{name:36s} vs fp64: HIP {e_hip:.2e}  CPU fp32 {e_cpu:.2e}")
@@ -328,3 +330,47 @@ def test_configs4_full_model_one_graphed_step_bf16_fp8():
             seg = opt_.flat_g[off:off + p_.numel()]
             assert torch.isfinite(seg).all() and float(seg.abs().max()) > 0, (tuple(p_.shape), off)
     assert float((m.optimizer_G.flat_p - w0).abs().max()) > 0
+
+
+def test_bf16_training_tracks_fp32_over_200_steps():
+    """Round-2 review item 4: is the benchmarked bf16 step a usable training step?  The same reduced-width configs[1] model
+    (ngf = ndf = 16, 512x256, 4 down-samplings, 9 blocks, 2-scale D), identical initial weights, four fixed batches cycled in
+    the same order, 200 graph-replayed optimisation steps in fp32 and in bf16: the four losses must stay inside a band
+    around the fp32 run at every checkpoint (the reference's AMP recipe, train.py:62-67,148-181, is the analogue).
+    Measured (tools/soak_pair.py, profiles/r03_soak_pair.log): largest deviation 14 % of the loss value (D_fake at step
+    125; GAN training is chaotic, the trajectories do not stay bit-close), mean 2.5 %."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import make_opt
+    from pix2pixhdaudiosr_amd.models.models import create_model
+
+    def run(fp16):
+        opt = make_opt(2, dtype_bf16=fp16)
+        opt.ngf, opt.ndf, opt.mask = 16, 16, False
+        torch.manual_seed(1234)
+        m = create_model(opt)
+        T = 255 * opt.hop_length
+        g = torch.Generator(device="cuda").manual_seed(7)
+        data = [(0.1 * torch.randn(2, T, device="cuda", generator=g), 0.1 * torch.randn(2, T, device="cuda", generator=g)) for _ in range(4)]
+        traj = []
+        for i in range(200):
+            ld = m.train_step_graphed(*data[i % 4])
+            if (i + 1) % 25 == 0:
+                traj.append({k: float(v) for k, v in ld.items()})
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+        del m
+        torch.cuda.empty_cache()
+        return traj
+
+    t32, t16 = run(False), run(True)
+    devs = []
+    for i, (a, b) in enumerate(zip(t32, t16)):
+        for k in a:
+            dev = abs(b[k] - a[k]) / max(abs(a[k]), 0.25)
+            devs.append(dev)
+            assert dev <= 0.3, (25 * (i + 1), k, a[k], b[k])
+    print(f"bf16 vs fp32 over 200 steps: max loss deviation {max(devs):.3f}, mean {sum(devs) / len(devs):.3f}")
+    assert sum(devs) / len(devs) <= 0.08
+    # both runs learn: the feature-matching loss falls by the same factor
+    assert t32[-1]["G_GAN_Feat"] < 0.9 * t32[0]["G_GAN_Feat"] and t16[-1]["G_GAN_Feat"] < 0.9 * t16[0]["G_GAN_Feat"]
