@@ -25,7 +25,6 @@ sys.path.insert(0, ROOT)
 
 FRAMES = 256                      # spectrogram frames per sample at 512x256
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-FP8_DENSE_PEAK_TFLOPS = 5000.0    # same guide: ~5 PF dense fp8
 M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd4 nb9 @512x256 (SURVEY 8a probe)
 M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
 
@@ -128,20 +127,21 @@ def time_mdct(batch):
     from pix2pixhdaudiosr_amd.models import mdct as MM
     from pix2pixhdaudiosr_amd.util.util import kbdwin
     out = {}
-    for n_fft, frames in ((1024, 256), (2048, 512)):
+    for n_fft, frames, rows in ((1024, 256, batch), (1024, 256, 2 * batch), (2048, 512, batch)):
         hop = n_fft // 2
         T = (frames - 1) * hop
         w = kbdwin(n_fft).cuda()
         tables = MM._Tables.get(n_fft, w.device)
-        x = 0.1 * torch.randn(batch, T, device="cuda")
+        x = 0.1 * torch.randn(rows, T, device="cuda")
         sp, _, nf = MM.frame_layout(batch, T, hop, n_fft, True)
         S = MM._run_mdct(x, n_fft, hop, n_fft, w, tables, sp, nf, 1.0)
         t_f = time_graphed(lambda: MM._run_mdct(x, n_fft, hop, n_fft, w, tables, sp, nf, 1.0))
         t_i = time_graphed(lambda: MM._run_imdct(S, n_fft, hop, n_fft, w, tables, n_fft // 2, T, 4.0 / n_fft))
-        nframes = batch * nf
+        nframes = rows * nf
         bytes_alg = nframes * 4 * n_fft          # (hop + n_fft/2) floats = 4 n_fft bytes per frame (4 KiB at n_fft 1024)
+        tag = "" if rows == batch else f"_rows{rows}"        # rows = 2 x batch: hr and lr of one step in ONE launch (encode_input)
         for name, t in (("mdct4", t_f), ("imdct4", t_i)):
-            out[f"{name}_n{n_fft}"] = {"shape": [batch, T], "frames": nframes, "us": t * 1e6, "frames_per_s": nframes / t,
+            out[f"{name}_n{n_fft}{tag}"] = {"shape": [rows, T], "frames": nframes, "us": t * 1e6, "frames_per_s": nframes / t,
                                        "GB_per_s": bytes_alg / t / 1e9, "frac_of_hbm_peak": bytes_alg / t / 1e12 / HBM_PEAK_TBS,
                                        "bytes_per_frame": 4 * n_fft}
     return out
@@ -460,10 +460,13 @@ def main():
                            "launches_timed": "forward launches only (gather pad_mode 1); the same-shaped input-gradient launches: dgrad_launch_us",
                            "dgrad_launch_us": None if sec_dgrad is None else sec_dgrad * 1e6}
         if a.fp8 and world == 1:
-            # the probed launches are the e4m3 forward of the trunk: price them against the dense fp8 peak, and the
-            # recorded HBM traffic (taken on the bf16 kernel) does not apply
-            out["roofline"].update({"peak": FP8_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / FP8_DENSE_PEAK_TFLOPS,
+            # the probed launches are the e4m3 forward of the trunk on the NON-scaled v_mfma_f32_32x32x16_fp8_fp8, which issues at
+            # the cycles of the bf16 form (MI355X_MICROARCH.md, matrix-core table): its ceiling is the bf16 peak, not the 5 PF
+            # of the block-scaled f8f6f4 instructions -- the launch is priced against 2.5 PF; the recorded HBM traffic (taken on
+            # the bf16 kernel) does not apply
+            out["roofline"].update({"peak": BF16_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS,
                                     "traffic": None, "traffic_source": None,
+                                    "peak_note": "non-scaled fp8 MFMA runs at the bf16 issue rate: priced against the bf16 dense peak",
                                     "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
         if world == 1:
             try:

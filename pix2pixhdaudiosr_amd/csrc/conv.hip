@@ -442,43 +442,51 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     // the tile, and the part that arrives LAST adds all parts in index order -- a fixed summation order whatever the
     // timing -- and carries on into the normal epilogue.  sc1 stores / loads: the parts run on different XCDs.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // partial out: 16-byte sc1 (write-through) stores, lane-interleaved = coalesced; in: the finisher's agent-scope acquire
-    // (fold_arrive_last) followed by PLAIN 16-byte loads -- the always-valid hand-over of MI355X_MICROARCH.md (sc1 stores
-    // drained by every wave + barrier + agent ticket | ticket + acquire + barrier + plain loads).  The loads are C++ loads:
-    // an inline-asm load would hand the compiler registers whose data has not landed yet.
-    constexpr int NQ = MR * NR * 4;                            // float4 pieces per thread
-    float* pbase = d.sk_part + ((size_t)sk_tile * d.sk_parts + sk_part) * (size_t)(BM * BN);
+    // partials travel as 16-byte pieces, lane-interleaved (coalesced), through buffer instructions with the sc0 sc1 cache
+    // policy on BOTH sides: write-through stores, and loads that are served from memory, not from this XCD's L2 -- an
+    // agent-scope acquire followed by plain loads read stale partials of the previous launch here (measured: wrong sums in
+    // the tail tiles), the per-XCD L2s are not coherent with each other.  Compiler-visible builtins: the waits are its.
+    constexpr int NQ = MR * NR * 4;                            // 16-byte pieces per thread
+    constexpr int kSc = 0x11;                                  // aux: bit 0 = sc0, bit 4 = sc1
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+    const size_t part_bytes = (size_t)BM * BN * 4;
+    const auto rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(d.sk_part + (size_t)sk_tile * d.sk_parts * (size_t)(BM * BN)), 0,
+                                                       (int)(d.sk_parts * part_bytes), 0x00020000);
+    const int lane_off = tid * 16;
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          const float* ptr = pbase + ((size_t)((i * NR + j) * 4 + q) * NT + tid) * 4;
-          asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(ptr), "v"(v) : "memory");
+          const u32x4 v = {__float_as_uint(acc[i][j][4 * q]), __float_as_uint(acc[i][j][4 * q + 1]),
+                           __float_as_uint(acc[i][j][4 * q + 2]), __float_as_uint(acc[i][j][4 * q + 3])};
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (int)(sk_part * part_bytes) + ((i * NR + j) * 4 + q) * NT * 16 + lane_off, 0, kSc);
         }
     if (!p2phd::fold_arrive_last(d.sk_ticket + sk_tile, (unsigned)d.sk_parts)) return;
-    const float* tbase = d.sk_part + (size_t)sk_tile * d.sk_parts * (size_t)(BM * BN);
 #pragma unroll
     for (int i = 0; i < MR; ++i)
 #pragma unroll
       for (int j = 0; j < NR; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // pieces in flight per batch: all of a part where the registers allow, 8 for the 128-accumulator tile (it spills otherwise)
+    constexpr int CH = MR * NR > 6 ? 8 : NQ;
+    static_assert(NQ % CH == 0, "piece batches");
     for (int pp = 0; pp < d.sk_parts; ++pp) {
-      const f32x4* pb = reinterpret_cast<const f32x4*>(tbase + (size_t)pp * (size_t)(BM * BN));
-      f32x4 v[NQ];
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) v[q] = pb[(size_t)q * NT + tid];
+      for (int q0 = 0; q0 < NQ; q0 += CH) {
+        u32x4 v[CH];
 #pragma unroll
-      for (int i = 0; i < MR; ++i)
+        for (int q = 0; q < CH; ++q) v[q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)(pp * part_bytes) + (q0 + q) * NT * 16 + lane_off, 0, kSc);
 #pragma unroll
-        for (int j = 0; j < NR; ++j)
+        for (int q = 0; q < CH; ++q) {
+          const int ij = (q0 + q) >> 2, qq = (q0 + q) & 3;
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[(i * NR + j) * 4 + q][e];
+          for (int e = 0; e < 4; ++e) acc[ij / NR][ij % NR][4 * qq + e] += __uint_as_float(v[q][e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);                      // keep the batches apart (hoisting every load at once spills)
+      }
     }
     __syncthreads();
   }
@@ -1703,7 +1711,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   if (!huge && force == 0 && sizeof(T) <= 2 && enough_px && !short_k && k % 192 == 0 && (k <= 384 || d.bs_out != nullptr || d.as_x != nullptr) &&
       2 * 448 * kRowBytes + tabb <= kLds && mt256 * (k / 192) >= 192)
     return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
-  if constexpr (sizeof(T) != 1) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments)
+  if constexpr (sizeof(T) == 2) {                              // (the 256 x 256 tile spills with the two-MFMA fp8 fragments; f32 never takes it)
     if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   if (big && bn == 128) {

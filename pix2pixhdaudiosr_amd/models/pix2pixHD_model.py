@@ -390,6 +390,10 @@ class Pix2PixHDModel(BaseModel):
 
     def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
         losses, sr_result = self._losses(lr_audio, hr_audio, noise, share_fake_pass=False)
+        # state of the staged step (cut activations, combined losses) belongs to train_step only: the reference-style
+        # forward() / backward() path never consumes it, and it would keep the autograd graph alive until the next forward
+        self._cuts = None
+        self._loss_G = self._loss_D = None
         return [losses, None if not infer else sr_result]
 
     def inference(self, lr_audio, inst, noise=None):

@@ -1,4 +1,12 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r2t
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/r2t/fetch -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-mdct > gpurun_out/r2t/fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/r2t/write -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-mdct > gpurun_out/r2t/write.log 2>&1
-ls gpurun_out/r2t/*/*/*counter_collection.csv; tail -1 gpurun_out/r2t/fetch.log | cut -c1-200
+#!/usr/bin/env bash
+# Memory-side traffic of one whole (eager) step: two separate --pmc passes, fresh output directories (see collect_profiles.sh).
+set -euo pipefail
+TAG="${1:-r03}"
+cd /tmp && export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}"
+OUT="gpurun_out/${TAG}t"
+rm -rf "$OUT/fetch" "$OUT/write"; mkdir -p "$OUT/fetch" "$OUT/write"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-mdct > "$OUT/fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -- python3 bench.py --steps 1 --warmup 1 --no-graph --no-cpu-baseline --no-mdct > "$OUT/write.log" 2>&1
+ls "$OUT"/*/*/*counter_collection.csv
+tail -n 1 "$OUT/fetch.log" | cut -c1-200
