@@ -224,6 +224,9 @@ def launch_ranks(n, argv):
     sys.exit(rc)
 
 
+_JSON_OUT = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,6 +238,9 @@ def main():
     ap.add_argument("--allow-eager-fallback", action="store_true",
                     help="keep measuring with the eager step if graph capture / replay fails (default: exit non-zero)")
     ap.add_argument("--no-mdct", action="store_true", help="skip the stand-alone MDCT4 / IMDCT4 measurement")
+    ap.add_argument("--no-probes", action="store_true",
+                    help="skip the extra eager steps of the dominant-kernel probe and the generator-only timing (profiling runs that "
+                         "count launches or bytes per step: tools/collect_step_traffic.sh)")
     ap.add_argument("--comm-cus", type=int, default=0,
                     help="data parallel: run the step on a stream whose CU mask leaves this many CUs to the RCCL kernels (0 = off)")
     ap.add_argument("--fp8", action="store_true",
@@ -243,6 +249,14 @@ def main():
 
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
+    # ONE JSON line on stdout, nothing else: libraries print banners there (RCCL 2.26 writes its version block to stdout
+    # when the first communicator is created), so fd 1 is pointed at stderr for the whole run and the line goes to a
+    # duplicate of the original stdout
+    global _JSON_OUT
+    if _JSON_OUT is None and ("WORLD_SIZE" in os.environ or a.gpus == 1):
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
     if "WORLD_SIZE" not in os.environ:
         if a.gpus > 1:
             launch_ranks(a.gpus, sys.argv[1:])                     # does not return
@@ -426,7 +440,7 @@ def main():
         sec_iso, flops = time_trunk_conv(a.batch)
         sec = sec_iso
         sec_dgrad = None
-        if world == 1:                                             # extra steps on one rank only would desynchronise the collectives
+        if world == 1 and not a.no_probes:                         # extra steps on one rank only would desynchronise the collectives
             import ctypes as C
             L = _ops.lib()
 
@@ -468,7 +482,7 @@ def main():
                                     "traffic": None, "traffic_source": None,
                                     "peak_note": "non-scaled fp8 MFMA runs at the bf16 issue rate: priced against the bf16 dense peak",
                                     "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
-        if world == 1:
+        if world == 1 and not a.no_probes:
             try:
                 tg = time_generator(model, a.batch)
                 gf = 6 * M_G * a.batch
@@ -485,7 +499,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             log("cpu baseline (oracle, batch 2: configs[1] and configs[0] networks, 1 + 3 steps each) ...")
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
     if dist_on:
         torch.distributed.barrier()                               # rank 0 is still measuring its dominant kernel
         torch.distributed.destroy_process_group()

@@ -53,7 +53,7 @@ def derive(paths, out, trunk_out):
                 for key, label in LABELS:
                     if key in r["Kernel_Name"]:
                         per[label][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
-    res = {"recorded": __import__("datetime").date.today().isoformat() + " (round 2)",
+    res = {"recorded": __import__("datetime").date.today().isoformat() + f" ({ROUND})",
            "how": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --pmc <one block per pass> -- python3 tools/pmc_targets.py "
                   "(FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | SQ_* issue counters), "
                   "summarised by tools/summarize_profile.py --derive",
@@ -91,7 +91,7 @@ def derive(paths, out, trunk_out):
                    "hbm_bytes_per_launch": t["memory_side_bytes_per_launch"], "algorithmic_bytes_per_launch": 61000000,
                    "note": "memory-side requests, Infinity-Cache hits included: 25 MB of activations + the 10.6 MB packed weight matrix "
                            "once per XCD L2 (85 MB) + 9-tap halo re-reads that miss L2; far below the HBM roof: the kernel is MFMA / LDS "
-                           "bound (mfma pipe busy fraction in profiles/r02_mfma_pmc.json)"}, open(trunk_out, "w"), indent=1)
+                           f"bound (mfma pipe busy fraction in profiles/{ROUND_TAG}_mfma_pmc.json)"}, open(trunk_out, "w"), indent=1)
         print("wrote", trunk_out)
 
 
@@ -111,25 +111,67 @@ def traffic(fetch_csv, write_csv, steps, out):
     tot_r = sum(2 * v[1] for v in acc.values()) * 1024 / steps / 1e9
     tot_w = sum(v[2] for v in acc.values()) * 1024 / steps / 1e9
     with open(out, "w") as f:
-        f.write("# Memory-side traffic of one training step (configs[1], B=32, bf16), round 2\n\n"
+        f.write(f"# Memory-side traffic of one training step (configs[1], B=32, bf16), {ROUND}\n\n"
                 "`rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, in a second pass, `--pmc WRITE_SIZE` on `python3 bench.py --steps 1 "
-                f"--warmup 1 --no-graph --no-cpu-baseline --no-mdct` ({steps} step-equivalents per pass); FETCH_SIZE x2 (gfx950 counts 64 B per "
+                f"--warmup 1 --no-graph --no-probes --no-cpu-baseline --no-mdct` ({steps} step-equivalents per pass); FETCH_SIZE x2 (gfx950 counts 64 B per "
                 "128-B request), WRITE_SIZE as is; Infinity-Cache hits included (upper bounds on HBM traffic); times are those of the "
                 "instrumented FETCH pass.\n\n"
-                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22).\n\n"
+                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22; round 2: 76.5 + 19.8).\n\n"
                 "| kernel | launches/step | read GB/step | written GB/step | time ms/step |\n|---|---|---|---|---|\n")
         for k, v in rows[:40]:
             f.write(f"| `{k[-70:]}` | {v[0] / steps:.1f} | {2 * v[1] * 1024 / steps / 1e9:.2f} | {v[2] * 1024 / steps / 1e9:.2f} | {v[3] / steps / 1e6:.2f} |\n")
     print("wrote", out, f"read {tot_r:.1f} GB written {tot_w:.1f} GB per step")
 
 
+def one_step(path, out):
+    """Per-kernel time of ONE graph-replayed step of a `bench.py` kernel trace: the dispatches between the discriminator's
+    Adam launch of one replay and the next (the last but one such interval: a timed step)."""
+    import re
+    with open(path) as f:
+        rows = list(csv.DictReader(f))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    adam = [i for i, r in enumerate(rows) if "adam_dev" in r["Kernel_Name"]]
+    pairs = list(zip(adam[1::2], adam[3::2]))
+    sizes = collections.Counter(b - a for a, b in pairs)
+    n_common = sizes.most_common(1)[0][0]                          # the replayed steps all have the same launch count
+    a, b = [p for p in pairs if p[1] - p[0] == n_common][-2]
+
+    def fam(n):
+        n = short(n).replace("void ", "")
+        n = re.sub(r"^\d+", "", n)
+        m = re.match(r"gconv_kernelI(DF16b|f|NS_5fp8_tE)Li(\d+)ELi(\d+)", n)
+        if m: return f"gconv_kernel<{m.group(2)}x{m.group(3)}>"
+        m = re.match(r"wgrad_kernelI(DF16b|f)Li(\d+)", n)
+        if m: return f"wgrad_kernel<{m.group(2)}>"
+        return re.sub(r"\(.*", "", re.sub(r"<.*", "", re.sub(r"I(DF16b|f).*", "", n)))[:44]
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows[a + 1:b + 1]:
+        k = fam(r["Kernel_Name"])
+        acc[k][0] += 1
+        acc[k][1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    tot = sum(v[1] for v in acc.values())
+    wall = (int(rows[b]["End_Timestamp"]) - int(rows[a]["End_Timestamp"])) / 1e3
+    with open(out, "w") as f:
+        f.write(f"# one graph-replayed step of bench.py under rocprofv3 --kernel-trace ({ROUND}): {b - a} kernel launches, "
+                f"{tot / 1e3:.2f} ms of kernel time in {wall / 1e3:.2f} ms of wall time\n")
+        f.write("kernel,launches,ms,percent\n")
+        for k, v in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            f.write(f"{k},{v[0]},{v[1] / 1e3:.3f},{100 * v[1] / tot:.1f}\n")
+    print("wrote", out, f"{b - a} launches {tot / 1e3:.2f} ms")
+
+
+ROUND_TAG = "r03"
+ROUND = "round 3"
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
+    ap.add_argument("--one-step")
     ap.add_argument("--trace"); ap.add_argument("--pmc", nargs="*"); ap.add_argument("--derive", nargs="*")
-    ap.add_argument("--trunk-out"); ap.add_argument("--traffic", nargs=2); ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--trunk-out"); ap.add_argument("--traffic", nargs=2); ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--out", required=True)
     a = ap.parse_args()
-    if a.trace: trace(a.trace, a.out)
+    if a.one_step: one_step(a.one_step, a.out)
+    elif a.trace: trace(a.trace, a.out)
     elif a.traffic: traffic(a.traffic[0], a.traffic[1], a.steps, a.out)
     elif a.derive: derive(a.derive, a.out, a.trunk_out)
     else: pmc(a.pmc, a.out)
