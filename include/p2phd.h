@@ -128,7 +128,16 @@ typedef struct p2phd_conv_desc {
   int32_t K, R, S;
   int32_t stride, pad, pad_mode, transposed, opad;
   int32_t dtype;
+  int32_t w_layout;   /* layout of the f32 master weights (and of dw): 0 = PyTorch ([K,C,R,S] / [C,K,R,S]), 1 = K-major [K][R][S][C] */
 } p2phd_conv_desc;
+
+/* K-major master weights (round 3): for plain stride-1 Conv2d layers without channel or K padding (the residual trunk, the
+ * discriminator's 256 -> 512 layers: 95 % of the parameters) the packed forward row [tap][channel] IS the master row when the
+ * optimiser keeps the weights as [K][R][S][C].  The forward pack is then a cast, the input-gradient pack a bf16 transpose per
+ * tap, and the weight gradient lands with coalesced rows instead of through a re-ordering tile.  The Python mirror hands such
+ * parameters to torch as permuted views of the flat buffer (state_dict and checkpoints are unchanged).
+ * p2phd_conv_kmajor_ok: 1 if desc (w_layout ignored) may set w_layout = 1. */
+int p2phd_conv_kmajor_ok(const p2phd_conv_desc* c);
 
 int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
 

@@ -36,6 +36,7 @@ SIGNATURES = {
     "p2phd_imdct2_fwd": (_i32, [_vp, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp]),
     "p2phd_channel_pitch": (_i32, [_i32]),
     "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "p2phd_conv_kmajor_ok": (_i32, [_vp]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
@@ -89,7 +90,7 @@ SIGNATURES = {
 class ConvDesc(C.Structure):
     """struct p2phd_conv_desc (include/p2phd.h)."""
     _fields_ = [(n, C.c_int32) for n in ("N", "C", "H", "W", "K", "R", "S", "stride", "pad", "pad_mode",
-                                         "transposed", "opad", "dtype")]
+                                         "transposed", "opad", "dtype", "w_layout")]
 
 _lib = None
 

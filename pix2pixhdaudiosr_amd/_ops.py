@@ -158,8 +158,8 @@ def _bwd_range(n):
 def _direct_grad(p):
     """True when `p.grad` is FlatAdam's view of its flat gradient buffer (optim.py marks the parameter)."""
     g = p.grad
-    return (getattr(p, "_p2phd_direct_grad", False) and g is not None and g.dtype == torch.float32 and g.is_contiguous()
-            and g.shape == p.shape)
+    return (getattr(p, "_p2phd_direct_grad", False) and g is not None and g.dtype == torch.float32
+            and (g.is_contiguous() or w_layout(g) == 1) and g.shape == p.shape)
 
 
 @contextlib.contextmanager
@@ -174,6 +174,24 @@ def no_weight_grad():
 
 def cpitch(c):
     return (c + 7) & ~7
+
+
+def w_layout(t):
+    """p2phd_conv_desc::w_layout of a conv weight (or weight-gradient) tensor of logical shape [K, C, R, S]: 0 = PyTorch
+    (contiguous), 1 = K-major -- storage order [K][R][S][C], what optim.FlatAdam gives the big stride-1 layers
+    (p2phd_conv_kmajor_ok) so that the packed forward row IS the master row."""
+    if t is None or t.dim() != 4:
+        return 0
+    K, Cc, R, S = t.shape
+    if t.stride() == (R * S * Cc, 1, S * Cc, Cc) and not (R * S == 1 and t.is_contiguous()) and Cc > 1:
+        return 1
+    return 0
+
+
+def kmajor_eligible(cin, cout, k, stride, transposed):
+    """Shape rule of p2phd_conv_kmajor_ok, geometry-free (the library checks it again on every call)."""
+    return (not transposed and stride == 1 and cin % 8 == 0 and cin >= 64 and cout >= 64 and k * k <= 16
+            and (k * k * cin) % 64 == 0 and os.environ.get("P2PHD_KMAJOR", "1") != "0")
 
 
 # Guard-band mode (tests / tools only; GPU AddressSanitizer is not available on this pool): every buffer this module
@@ -410,16 +428,14 @@ class ConvSpec:
             return hit[1]
         nbytes = lib().p2phd_conv_fp8_packed_bytes(C.byref(d))
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
-        w = weight.detach()
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
+        w = _master_weight(weight, d)
         check(lib().p2phd_conv_fp8_pack_weights(C.byref(d), ptr(w), ptr(buf), stream_ptr()), "conv_fp8_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
 
-    def desc(self, N, H, W, dtype):
+    def desc(self, N, H, W, dtype, layout=0):
         return ConvDesc(N, self.cin, H, W, self.cout, self.k, self.k, self.stride, self.pad, self.pad_mode,
-                        int(self.transposed), self.opad, dt_code(dtype))
+                        int(self.transposed), self.opad, dt_code(dtype), int(layout))
 
     def out_size(self, d):
         ho, wo = C.c_int32(), C.c_int32()
@@ -436,12 +452,22 @@ class ConvSpec:
             return hit[1]
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
-        w = weight.detach()
-        if w.dtype != torch.float32 or not w.is_contiguous():
-            w = w.float().contiguous()
+        w = _master_weight(weight, d)
         check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
+
+
+def _master_weight(weight, d):
+    """The f32 master weights in the layout d.w_layout names (a K-major parameter is handed over as it lies in memory)."""
+    w = weight.detach()
+    if d.w_layout == 1:
+        if w.dtype != torch.float32 or w_layout(w) != 1:
+            raise _lib.P2PHDError("conv: descriptor says K-major master weights but the tensor is not a float32 [K][R][S][C] view")
+        return w
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    return w
 
 
 # Fused first pass of the producer's InstanceNorm backward (p2phd_conv_dgrad_bsum): when the tensor a conv block reads is the
@@ -476,7 +502,7 @@ class ConvBlockFn(torch.autograd.Function):
         N, H, W, Cp_in = x.shape
         if Cp_in != cpitch(spec.cin):
             raise _lib.P2PHDError(f"conv: input has channel pitch {Cp_in}, layer expects {cpitch(spec.cin)} ({spec.cin} channels)")
-        d = spec.desc(N, H, W, x.dtype)
+        d = spec.desc(N, H, W, x.dtype, w_layout(weight))
         Ho, Wo = spec.out_size(d)
         L = lib()
         Cp_out = cpitch(spec.cout)
@@ -540,7 +566,7 @@ class ConvBlockFn(torch.autograd.Function):
             lo, hi = rng
             x, y, g = x[lo:hi], y[lo:hi], g[lo:hi]
             stats = None if stats is None else stats[lo:hi]
-            d = spec.desc(hi - lo, x.shape[1], x.shape[2], x.dtype)
+            d = spec.desc(hi - lo, x.shape[1], x.shape[2], x.dtype, d.w_layout)
         parked, ctx._parked = ctx._parked, None
         dy_done, ctx._dy_done = ctx._dy_done, None                 # (consumed once: a marker must not outlive its backward pass)
         # the consumer's input-gradient kernel (p2phd_conv_dgrad_act) may have applied this block's activation derivative
@@ -605,17 +631,18 @@ class ConvBlockFn(torch.autograd.Function):
         if need_w:
             gw = weight.grad if direct else empty(tuple(weight.shape), torch.float32, y.device)
             wgrad = L.p2phd_conv_wgrad_acc if direct else L.p2phd_conv_wgrad
+            dwd = d if w_layout(gw) == d.w_layout else spec.desc(d.N, d.H, d.W, y.dtype, w_layout(gw))   # layout of what is WRITTEN
             if direct and _SIDE["on"] and not _GUARD["on"]:
                 side = _side_stream(y.device)
                 side.wait_stream(torch.cuda.current_stream())      # dy (and a bias gradient riding on its pass) are ready
                 with torch.cuda.stream(side):
-                    ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device, "side")
-                    check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+                    ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device, "side")
+                    check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
                 _SIDE["keep"].append((x, dy))
                 _SIDE["used"] = True
             else:
-                ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), y.device)
-                check(wgrad(C.byref(d), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+                ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device)
+                check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
             if direct:
                 gw = gb = None
         gx_full = None

@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(256) void pack_kernel(GDesc d, p2phd::WMap m, const
       int ta2 = ta, tb2 = tb;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        v[i] = src[(d.wr0 + ta2 * d.wr_step) * m.S + d.ws0 + tb2 * d.ws_step];
+        v[i] = src[((d.wr0 + ta2 * d.wr_step) * m.S + d.ws0 + tb2 * d.ws_step) * m.s_tap];
         if (t0 + i + 1 < T_taps && ++tb2 == ntw) { tb2 = 0; ++ta2; }
       }
 #pragma unroll
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256) void pack_transposed_kernel(GDesc d, p2phd::WM
 
 inline bool transposed_map(const GDesc& d, const p2phd::WMap& m) {
   const int T_taps = d.nth * d.ntw;
-  if (!(T_taps <= 16 && m.s_row >= 1 && m.s_row <= 16 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.inner > 0 && m.rows > 0 &&
+  if (!(T_taps <= 16 && m.s_tap == 1 && m.s_row >= 1 && m.s_row <= 16 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.inner > 0 && m.rows > 0 &&
         m.s_inner >= (long)m.rows * m.s_row))
     return false;
   for (int t = 0; t < T_taps; ++t) {                             // every tap must address inside the R*S block
@@ -1339,8 +1339,90 @@ inline bool transposed_map(const GDesc& d, const p2phd::WMap& m) {
 
 inline bool dense_map(const GDesc& d, const p2phd::WMap& m) {
   const int T_taps = d.nth * d.ntw;
-  return T_taps <= 16 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.s_inner == T_taps && d.wr0 == 0 && d.wr_step == 1 &&
+  return T_taps <= 16 && m.s_tap == 1 && m.c_mod >= m.inner && m.row_mod >= m.rows && m.s_inner == T_taps && d.wr0 == 0 && d.wr_step == 1 &&
          d.ws0 == 0 && d.ws_step == 1 && d.ntw == m.S && m.inner > 0 && m.rows > 0;
+}
+
+// ---- K-major master weights [rows = K][tap][inner = C] (p2phd_conv_desc::w_layout = 1) ------------------------------------------
+// forward pack / weight gradient: the packed row [tap][Cp] is the master row (Cp == C, taps in order)
+inline bool kmajor_dense_map(const GDesc& d, const p2phd::WMap& m) {
+  const int T_taps = d.nth * d.ntw;
+  return m.s_inner == 1 && m.s_tap == m.inner && m.s_row == (long)T_taps * m.inner && d.Cp_in == m.inner && m.c_mod >= m.inner &&
+         m.row_mod >= m.rows && d.wr0 == 0 && d.wr_step == 1 && d.ws0 == 0 && d.ws_step == 1 && d.ntw == m.S && m.inner > 0 && m.rows > 0;
+}
+// input-gradient pack: packed rows = C (master inner index), packed inner = K (master rows): a transpose per tap
+inline bool kmajor_transposed_map(const GDesc& d, const p2phd::WMap& m) {
+  const int T_taps = d.nth * d.ntw;
+  return T_taps <= 16 && m.s_row == 1 && m.s_tap == m.rows && m.s_inner == (long)T_taps * m.rows && m.c_mod >= m.inner &&
+         m.row_mod >= m.rows && d.ntw * d.nth == T_taps && m.inner > 0 && m.rows > 0;
+}
+
+// wp[row][kk] = T(w[row][kk]) for kk < T_taps * C, zero in the K tail and in the padding rows: a cast, float4 in / 8 or 16 bytes out
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kmajor_dense_kernel(const float* __restrict__ w, T* __restrict__ wp, int rows, int rows_pad,
+                                                                int row_len, int KK) {
+  const long total4 = (long)rows_pad * (KK / 4);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / (KK / 4)), k4 = (int)(e - (long)row * (KK / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < rows && k4 < row_len) v = *reinterpret_cast<const float4*>(w + (size_t)row * row_len + k4);    // row_len % 8 == 0
+    T* o = wp + (size_t)row * KK + k4;
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 b = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+      *reinterpret_cast<bf16x4*>(o) = b;
+    } else {
+      *reinterpret_cast<float4*>(o) = v;
+    }
+  }
+}
+
+// wp[c][t'][k] = T(w[k][tap(t')][c]): per packed tap a 64 (k) x 64 (c) tile through LDS, reads coalesced along c, writes along k
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kmajor_transposed_kernel(GDesc d, p2phd::WMap m, const float* __restrict__ w, T* __restrict__ wp,
+                                                                     int rows_pad) {
+  __shared__ float tile[64][65];
+  const int T_taps = d.nth * d.ntw, Cp = d.Cp_in, KK = d.KK;
+  const int tx = threadIdx.x, ty = threadIdx.y;                  // (64, 4)
+  const int k0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tp = blockIdx.z;
+  const int ta = tp / d.ntw, tb = tp - ta * d.ntw;
+  const long tap = ((long)(d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step) * m.s_tap;   // master offset of this packed tap
+  // master element (k, c): w[k * s_inner + tap + c]   (m.rows = C, m.inner = K)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = k0 + ty + 4 * i, c = c0 + tx;
+    tile[ty + 4 * i][tx] = (k < m.inner && c < m.rows) ? w[(size_t)k * m.s_inner + tap + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, k = k0 + tx;
+    if (c < rows_pad && k < Cp) wp[(size_t)c * KK + (size_t)tp * Cp + k] = from_f<T>(tile[tx][ty + 4 * i]);
+  }
+  if (blockIdx.x == 0 && tp == 0) {                                // zero tail of the padded K extent of these 64 rows
+    for (int r = ty; r < 64; r += 4) {
+      const int c = c0 + r;
+      if (c >= rows_pad) break;
+      for (int kk = T_taps * Cp + tx; kk < KK; kk += 64) wp[(size_t)c * KK + kk] = from_f<T>(0.f);
+    }
+  }
+}
+
+// dw[row][kk] (+)= sum_z slab[z][row][kk], kk < T_taps * C: the weight gradient of a K-major layer lands with whole rows
+__global__ __launch_bounds__(256) void unpack_kmajor_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int rows, int row_len,
+                                                            int KK, int splits, long slab_elems, int accumulate) {
+  const int r4 = row_len / 4;
+  const long total4 = (long)rows * r4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / r4), k4 = (int)(e - (long)row * r4) * 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < splits; ++z) {                           // fixed order: reproducible
+      const float4 v = *reinterpret_cast<const float4*>(dwp + (size_t)z * slab_elems + (size_t)row * KK + k4);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(dw + (size_t)row * row_len + k4);
+    if (accumulate) { const float4 p = *o; a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w; }
+    *o = a;
+  }
 }
 
 // Packed weights of a merged sub-pixel launch (stride 2, transposed form):
@@ -1390,7 +1472,7 @@ __global__ __launch_bounds__(256) void unpack_grad_kernel(GDesc d, p2phd::WMap m
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         if (t0 + i < T_taps) {
-          float* o = dst + (d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step;
+          float* o = dst + ((d.wr0 + ta * d.wr_step) * m.S + d.ws0 + tb * d.ws_step) * m.s_tap;
           *o = accumulate ? *o + v[i] : v[i];
           if (++tb == ntw) { tb = 0; ++ta; }
         }
@@ -1436,13 +1518,14 @@ __global__ __launch_bounds__(256) void pack_fp8_kernel(GDesc d, p2phd::WMap m, c
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int row = (int)(e / c4n), c = (int)(e - (long)row * c4n) * 4;
     const bool row_ok = row < m.rows;
-    const float* src = w + (row_ok ? (long)row * m.s_row : 0) + (long)min(c, max(m.inner - 4, 0)) * T_taps;
+    // element (row, channel cc, tap t) of the master tensor: PyTorch layout s_inner = T_taps, s_tap = 1; K-major s_inner = 1, s_tap = C
+    const float* src = w + (row_ok ? (long)row * m.s_row : 0) + (long)min(c, max(m.inner - 4, 0)) * m.s_inner;
     for (int t0 = 0; t0 < T_taps; t0 += 4) {
       float v[4][4];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[i][u] = src[i * T_taps + min(t0 + u, T_taps - 1)];       // unconditional, clamped
+        for (int u = 0; u < 4; ++u) v[i][u] = src[i * m.s_inner + (long)min(t0 + u, T_taps - 1) * m.s_tap];   // unconditional, clamped
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (t0 + u >= T_taps) break;
@@ -1881,7 +1964,12 @@ int launch_wgrad(const GDesc& d_in, const WMap& m, int dtype, const void* rows, 
   }
   if (int rc = check_launch("wgrad")) return rc;
   if (m.rows > 0 && m.inner > 0) {
-    if (dense_map(d, m)) {
+    if (kmajor_dense_map(d, m)) {
+      const int row_len = d.nth * d.ntw * m.inner;
+      const long total4 = (long)m.rows * (row_len / 4);
+      hipLaunchKernelGGL(unpack_kmajor_kernel, dim3((unsigned)std::min<long>((total4 + 255) / 256, 8192)), dim3(256), 0, st, dwp, dw, m.rows,
+                         row_len, d.KK, splits, slab, accumulate);
+    } else if (dense_map(d, m)) {
       const dim3 grid((unsigned)((m.inner + 63) / 64), (unsigned)((m.rows + 3) / 4));
       const int tt = d.nth * d.ntw;
       if (tt == 9) hipLaunchKernelGGL(unpack_dense_kernel<9>, grid, dim3(64, 4), 0, st, d, m, dwp, dw, splits, slab, accumulate);
@@ -1908,6 +1996,24 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
 
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
   if (rows_pad <= 0) return P2PHD_OK;
+  if (kmajor_dense_map(d, m) && d.KK % 4 == 0) {
+    const int row_len = d.nth * d.ntw * m.inner;
+    const long total4 = (long)rows_pad * (d.KK / 4);
+    const dim3 grid((unsigned)std::min<long>((total4 + 255) / 256, 8192));
+    if (dtype == P2PHD_BF16)
+      hipLaunchKernelGGL(pack_kmajor_dense_kernel<bf16_t>, grid, dim3(256), 0, st, w, (bf16_t*)wp, m.rows, rows_pad, row_len, d.KK);
+    else
+      hipLaunchKernelGGL(pack_kmajor_dense_kernel<float>, grid, dim3(256), 0, st, w, (float*)wp, m.rows, rows_pad, row_len, d.KK);
+    return check_launch("pack_weights(k-major)");
+  }
+  if (kmajor_transposed_map(d, m)) {
+    const dim3 grid((unsigned)((std::max(m.inner, d.Cp_in) + 63) / 64), (unsigned)((rows_pad + 63) / 64), (unsigned)(d.nth * d.ntw));
+    if (dtype == P2PHD_BF16)
+      hipLaunchKernelGGL(pack_kmajor_transposed_kernel<bf16_t>, grid, dim3(64, 4), 0, st, d, m, w, (bf16_t*)wp, rows_pad);
+    else
+      hipLaunchKernelGGL(pack_kmajor_transposed_kernel<float>, grid, dim3(64, 4), 0, st, d, m, w, (float*)wp, rows_pad);
+    return check_launch("pack_weights(k-major transposed)");
+  }
   if (dense_map(d, m)) {
     const dim3 dgrid((unsigned)((d.Cp_in + 63) / 64), (unsigned)((rows_pad + 3) / 4));
     if (dtype == P2PHD_BF16)

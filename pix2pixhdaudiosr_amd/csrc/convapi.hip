@@ -28,6 +28,13 @@ void out_size(const p2phd_conv_desc* c, int* Ho, int* Wo) {
   }
 }
 
+// K-major master weights ([K][R][S][C], round 3): plain stride-1 Conv2d whose packed forward row IS the master row -- no
+// channel padding (C % 8 == 0), no K padding (R*S*C % 64 == 0), no W-fold / dedicated 7x7 path, a weight-gradient tile height
+bool kmajor_shape_ok(const p2phd_conv_desc* c) {
+  return !c->transposed && c->stride == 1 && c->C % 8 == 0 && c->C >= 64 && c->K >= 64 && c->R * c->S <= 16 &&
+         (c->R * c->S * c->C) % 64 == 0 && c->K > 4 && c->C > 4;
+}
+
 int check_desc(const p2phd_conv_desc* c) {
   P2PHD_REQUIRE(c != nullptr, "conv: null descriptor");
   P2PHD_REQUIRE(c->N >= 0 && c->C >= 1 && c->H >= 1 && c->W >= 1 && c->K >= 1 && c->R >= 1 && c->S >= 1, "conv: bad sizes");
@@ -38,6 +45,8 @@ int check_desc(const p2phd_conv_desc* c) {
     P2PHD_REQUIRE(!c->transposed, "conv: reflect padding is not defined for ConvTranspose2d");
     P2PHD_REQUIRE(c->pad < c->H && c->pad < c->W, "conv: reflect padding %d needs a larger image than %dx%d", c->pad, c->H, c->W);
   }
+  P2PHD_REQUIRE(c->w_layout == 0 || c->w_layout == 1, "conv: w_layout must be 0 (PyTorch) or 1 (K-major)");
+  P2PHD_REQUIRE(c->w_layout == 0 || kmajor_shape_ok(c), "conv: this layer cannot keep its master weights K-major (p2phd_conv_kmajor_ok)");
   if (c->transposed) P2PHD_REQUIRE(c->opad >= 0 && c->opad < c->stride, "conv: output_padding must be < stride");
   else P2PHD_REQUIRE(c->H + 2 * c->pad >= c->R && c->W + 2 * c->pad >= c->S, "conv: kernel larger than padded input");
   int Ho, Wo;
@@ -192,15 +201,15 @@ Plan cfold_fwd_plan(const p2phd_conv_desc* c, int Ho, int Wo) {
 
 WMap kfold_rows_map(const p2phd_conv_desc* c) {     // rows (tw,k), inner c
   const long RS = (long)c->R * c->S;
-  return WMap{c->S * c->K, c->C, c->C * RS, RS, c->K, 1, c->C, 0, c->S};
+  return WMap{c->S * c->K, c->C, c->C * RS, RS, c->K, 1, c->C, 0, c->S, 1};
 }
 WMap kfold_inner_map(const p2phd_conv_desc* c) {    // rows c, inner (tw,k)
   const long RS = (long)c->R * c->S;
-  return WMap{c->C, c->S * c->K, RS, c->C * RS, c->C, 0, c->K, 1, c->S};
+  return WMap{c->C, c->S * c->K, RS, c->C * RS, c->C, 0, c->K, 1, c->S, 1};
 }
 WMap cfold_map(const p2phd_conv_desc* c) {          // rows k, inner (tw,c)
   const long RS = (long)c->R * c->S;
-  return WMap{c->K, c->S * c->C, c->C * RS, RS, c->K, 0, c->C, 1, c->S};
+  return WMap{c->K, c->S * c->C, c->C * RS, RS, c->K, 0, c->C, 1, c->S, 1};
 }
 
 // which: 0 = forward, 1 = input gradient
@@ -217,7 +226,7 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
     plans.push_back(kfold_dgrad_plan(c, Ho, Wo)); *m = kfold_inner_map(c);
   } else if (which == 0 && !c->transposed) {
     plans.push_back(direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode));
-    *m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
+    *m = c->w_layout == 1 ? plain_map(c->K, c->C, c->C * RS, 1, c->S, c->C) : plain_map(c->K, c->C, c->C * RS, RS, c->S);
   } else if (which == 0 && c->transposed) {
     Plan mp;
     *m = plain_map(c->K, c->C, RS, c->K * RS, c->S);                          // weight [C][K][R][S]
@@ -227,6 +236,7 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
     const int P = c->pad_mode == 1 ? c->pad : 0;                               // reflect: gradient on the padded grid
     Plan mp;
     *m = plain_map(c->C, c->K, RS, c->C * RS, c->S);                          // weight [K][C][R][S]
+    if (c->w_layout == 1) *m = plain_map(c->C, c->K, 1, c->C * RS, c->S, c->C);   // ... kept as [K][R][S][C]
     if (c->stride == 2 && merged_plan(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->pad_mode == 1 ? 0 : c->pad, &mp))
       plans.push_back(mp);
     else
@@ -251,6 +261,15 @@ size_t folded_x_bytes(const p2phd_conv_desc* c, int Wo) {
 }  // namespace
 
 extern "C" int p2phd_channel_pitch(int channels) { return p2phd::cpitch(channels); }
+
+extern "C" int p2phd_conv_kmajor_ok(const p2phd_conv_desc* c) {
+  if (c == nullptr) return 0;
+  p2phd_conv_desc t = *c;
+  t.w_layout = 0;
+  if (check_desc(&t) != P2PHD_OK) return 0;
+  return (kmajor_shape_ok(c) && fold_mode(c) == FOLD_NONE && !c7_fast_shape(c) && !c7_out_shape(c) && !c7_dgrad_shape(c) &&
+          !thin_wgrad_kind(c)) ? 1 : 0;
+}
 
 extern "C" int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo) {
   if (int rc = check_desc(c)) return rc;
@@ -421,7 +440,7 @@ extern "C" int p2phd_conv_fp8_pack_weights(const p2phd_conv_desc* c, const float
   Plan p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
   p.d.KK = c->R * c->S * c->C;
   const long RS = (long)c->R * c->S;
-  const WMap m = plain_map(c->K, c->C, c->C * RS, RS, c->S);
+  const WMap m = c->w_layout == 1 ? plain_map(c->K, c->C, c->C * RS, 1, c->S, c->C) : plain_map(c->K, c->C, c->C * RS, RS, c->S);
   char* tail = static_cast<char*>(packed8) + fp8_weight_bytes(c);
   return launch_pack_fp8(p.d, m, w, packed8, p.rows_pad, reinterpret_cast<float*>(tail), reinterpret_cast<unsigned*>(tail + 16),
                          (hipStream_t)stream);
@@ -613,6 +632,7 @@ void wgrad_setup(const p2phd_conv_desc* c, WgradSetup* w) {
   } else if (!c->transposed) {     // dW[k][c][r][s] = sum dy[n,ho,wo,k] * x[n, ho*s-pad+r, wo*s-pad+s', c]
     w->p = direct_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, c->pad_mode);
     w->m = plain_map(c->K, c->C, c->C * RS, RS, c->S); w->M = c->K; w->Cp_r = cpitch(c->K);
+    if (c->w_layout == 1) w->m = plain_map(c->K, c->C, c->C * RS, 1, c->S, c->C);
   } else {                         // dW[ci][co][r][s] = sum x[n,i,j,ci] * dy[n, i*s-pad+r, j*s-pad+s', co]
     w->p = direct_plan(c->N, Ho, Wo, c->K, c->H, c->W, c->C, c->R, c->S, c->stride, c->pad, 0);
     w->m = plain_map(c->C, c->K, c->K * RS, RS, c->S); w->M = c->C; w->Cp_r = cpitch(c->C);

@@ -44,15 +44,17 @@ struct GDesc {
 //   offset(row, c, r, s) = (row % row_mod) * s_row + (row / row_mod) * s_rowq
 //                        + (c % c_mod) * s_inner + (c / c_mod) * s_innerq + r * S + s
 // row_mod / c_mod split a folded index (horizontal tap, channel) when the W taps ride on the channel axis.
+//                        + ((r * S + s) * s_tap)          [s_tap = 1 for PyTorch layouts; = C for the K-major master layout]
 struct WMap {
   int rows, inner;
   long s_row, s_inner;
   int row_mod; long s_rowq;
   int c_mod; long s_innerq;
   int S;
+  long s_tap;
 };
-inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S) {
-  return WMap{rows, inner, s_row, s_inner, rows > 0 ? rows : 1, 0, inner > 0 ? inner : 1, 0, S};
+inline WMap plain_map(int rows, int inner, long s_row, long s_inner, int S, long s_tap = 1) {
+  return WMap{rows, inner, s_row, s_inner, rows > 0 ? rows : 1, 0, inner > 0 ? inner : 1, 0, S, s_tap};
 }
 
 // operand type code of the fp8 forward launches (not part of the public dtype enum: activations stay bf16 at the ABI)

@@ -22,7 +22,7 @@ class BaseModel(torch.nn.Module):
         """fp32 CPU state_dict under the reference's file name; the network itself stays on the GPU."""
         os.makedirs(self.save_dir, exist_ok=True)
         path = os.path.join(self.save_dir, '%s_net_%s.pth' % (epoch_label, network_label))
-        torch.save({k: v.detach().float().cpu() for k, v in network.state_dict().items()}, path)
+        torch.save({k: v.detach().float().cpu().contiguous() for k, v in network.state_dict().items()}, path)   # (K-major parameters are permuted views)
 
     def load_network(self, network, network_label, epoch_label, save_dir=''):
         """Three-tier tolerant load of the reference (base_model.py:51-89): exact -> keys that exist here ->

@@ -65,6 +65,7 @@ def define_G(input_nc, output_nc, ngf, netG, n_downsample_global=3, n_blocks_glo
     net.apply(weights_init)
     if dtype is not None:
         net.compute_dtype = dtype
+    net.compile_all()
     return net
 
 
@@ -80,6 +81,7 @@ def define_D(input_nc, ndf, n_layers_D, norm='instance', use_sigmoid=False, num_
     net.apply(weights_init)
     if dtype is not None:
         net.compute_dtype = dtype
+    net.compile_all()
     return net
 
 
@@ -104,6 +106,10 @@ def _one(v):
 class _ConvStep:
     def __init__(self, conv, spec):
         self.conv, self.spec = conv, spec
+        # big stride-1 layers (the residual trunk, D 256 -> 512): optim.FlatAdam keeps their master weights K-major
+        # ([K][R][S][C]: the packed forward row IS the master row, see include/p2phd.h) and hands torch a permuted view
+        if _ops.kmajor_eligible(spec.cin, spec.cout, spec.k, spec.stride, spec.transposed):
+            conv.weight._p2phd_kmajor = True
 
     def run(self, x, residual=None, link=None, exclusive=False):
         return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link, exclusive)
@@ -235,6 +241,14 @@ class _HipNet(nn.Module):
         if name not in cache:
             cache[name] = _compile(getattr(self, name))
         return cache[name]
+
+    def compile_all(self):
+        """Compile every Sequential now (specs only, nothing touches the GPU): marks the parameters whose master copy the
+        optimiser should keep K-major BEFORE the optimiser lays out its flat buffers."""
+        for name, mod in self.named_children():
+            if isinstance(mod, nn.Sequential):
+                self._steps(name)
+        return self
 
     def _to_phys(self, x):
         if not x.is_cuda:

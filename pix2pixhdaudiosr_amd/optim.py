@@ -35,9 +35,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         with torch.no_grad():
             for p, o in zip(params, offs):
-                n = p.numel()
-                self.flat_p[o:o + n].copy_(p.detach().reshape(-1).float())
-                p.data = self.flat_p[o:o + n].view(p.shape)
+                v = self._view(self.flat_p, p, o)
+                v.copy_(p.detach().float())
+                p.data = v
         self._install_grad_views()
         self.step_count = 0
         # learning rate and step counter live on the device (p2phd_adam_step_dev): a captured step replays unchanged
@@ -59,9 +59,20 @@ class FlatAdam(torch.optim.Optimizer):
         self._waits = 0
         _ops.bump_weight_epoch()
 
+    @staticmethod
+    def _view(flat, p, o):
+        """The slice of a flat buffer that holds parameter p, shaped like p.  Conv weights marked K-major
+        (networks._ConvStep: the big stride-1 layers) are STORED [K][R][S][C] -- the layout the kernels' packed rows have --
+        and shown to torch as the permuted [K, C, R, S] view: state_dict, initialisers and checkpoints see nothing new."""
+        n = p.numel()
+        if getattr(p, "_p2phd_kmajor", False) and p.dim() == 4:
+            K, Cc, R, S = p.shape
+            return flat[o:o + n].view(K, R, S, Cc).permute(0, 3, 1, 2)
+        return flat[o:o + n].view(p.shape)
+
     def _install_grad_views(self):
         for p, o in zip(self._params, self._offs):
-            v = self.flat_g[o:o + p.numel()].view(p.shape)
+            v = self._view(self.flat_g, p, o)
             if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                 if p.grad is not None:
                     v.copy_(p.grad)

@@ -665,3 +665,53 @@ def test_fp8_forward_against_an_oracle_fed_the_quantised_operands(geom):
     e = rel_err(got.numpy(), ref.numpy())
     print(f"fp8 forward vs oracle on quantised operands: rel L2 {e:.2e}")
     assert e < 1e-2, e
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 1.2e-2)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(64, 128, 3, 1, 1, (2, 12, 10)), (128, 64, 4, 2, 0, (2, 9, 7)), (192, 96, 3, 1, 1, (1, 8, 8))],
+                         ids=["c3_reflect", "k4_zero", "odd_channels"])
+def test_kmajor_master_weights(dtype, tol, geom):
+    """Round 3: optim.FlatAdam keeps the master weights of the big stride-1 layers K-major ([K][R][S][C]) and hands torch a
+    permuted view; p2phd_conv_desc.w_layout = 1 selects the cast / per-tap-transpose packs and the row-wise weight-gradient
+    landing.  Same layer, same numbers as the PyTorch layout: forward, input gradient, weight gradient (written straight into
+    the optimiser's K-major gradient buffer), one Adam step."""
+    import ctypes as C
+    from pix2pixhdaudiosr_amd import _ops
+    from pix2pixhdaudiosr_amd.optim import FlatAdam
+    cin, cout, k, pad, pad_mode, (N, H, W) = geom
+    spec = _ops.ConvSpec(cin, cout, k, 1, pad, pad_mode, False, 0, True, _ops.ACT_RELU)
+    assert _ops.lib().p2phd_conv_kmajor_ok(C.byref(spec.desc(N, H, W, dtype))) == 1
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(N, cin, H, W, generator=g)
+    w0 = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    cot = None
+    res = {}
+    for layout in (0, 1):
+        w = torch.nn.Parameter(w0.clone().cuda())
+        if layout:
+            w._p2phd_kmajor = True
+        opt = FlatAdam([w], lr=1e-3)
+        assert _ops.w_layout(w) == layout and _ops.w_layout(w.grad) == layout
+        assert torch.equal(w.detach().cpu(), w0)                                   # the view shows the same tensor
+        spec = _ops.ConvSpec(cin, cout, k, 1, pad, pad_mode, False, 0, True, _ops.ACT_RELU)
+        xd = x.cuda().requires_grad_(True)
+        y = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(dtype, xd), w, None, spec), cout)
+        if cot is None:
+            cot = torch.randn(y.shape, generator=g).cuda()
+        opt.zero_grad()
+        (y * cot).sum().backward()
+        gw = w.grad.detach().clone()
+        opt.step()
+        torch.cuda.synchronize()
+        res[layout] = (y.detach().cpu(), xd.grad.cpu(), gw.cpu(), w.detach().cpu().clone())
+    for a, b, name in zip(res[1], res[0], ("y", "dx", "dw", "w_after")):
+        assert a.shape == b.shape
+        e = rel_err(a.numpy(), b.numpy())
+        assert e < (tol if name != "w_after" else 1e-3), (name, e)
+    if dtype == torch.float32:                                                      # ... and both equal the oracle
+        xo, wo = x.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        yo = F.relu(F.instance_norm(F.conv2d(F.pad(xo, (pad,) * 4, mode="reflect") if pad_mode else xo, wo,
+                                             padding=0 if pad_mode else pad), eps=1e-5))
+        go = torch.autograd.grad((yo * cot.cpu()).sum(), [xo, wo])
+        assert rel_err(res[1][0].numpy(), yo.detach().numpy()) < 1e-4
+        assert rel_err(res[1][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(res[1][2].numpy(), go[1].numpy()) < 3e-4
