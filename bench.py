@@ -437,6 +437,12 @@ def main():
         # launches of two extra eager steps (the graph-replayed steps above run exactly these kernels).  The
         # stand-alone back-to-back figure is logged too: 20 MFMA-bound launches in a row run at a lower sustained clock.
         from pix2pixhdaudiosr_amd import _ops
+        if a.no_probes:                                            # byte / launch counting runs: nothing beyond the steps themselves
+            print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)
+            if dist_on:
+                torch.distributed.barrier()
+                torch.distributed.destroy_process_group()
+            return
         sec_iso, flops = time_trunk_conv(a.batch)
         sec = sec_iso
         sec_dgrad = None
