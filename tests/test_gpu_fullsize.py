@@ -374,3 +374,32 @@ def test_bf16_training_tracks_fp32_over_200_steps():
     assert sum(devs) / len(devs) <= 0.08
     # both runs learn: the feature-matching loss falls by the same factor
     assert t32[-1]["G_GAN_Feat"] < 0.9 * t32[0]["G_GAN_Feat"] and t16[-1]["G_GAN_Feat"] < 0.9 * t16[0]["G_GAN_Feat"]
+
+
+def test_configs3_per_rank_step_local_enhancer_bf16_batch32():
+    """BASELINE configs[3] is configs[2]'s generator (GEN_VCTK_G3L2_48ngf as opt.txt reads it: LocalEnhancer ngf 48, 4 global
+    down-samplings, 3 global blocks, 1 local enhancer, 2 local blocks) in bf16 at per-GPU batch 32 on 8 GPUs.  What one rank
+    runs -- the graphed bf16 step of that model at B = 32, 512x256 -- runs here on one GPU (the exchange itself:
+    tests/test_gpu_dp.py, test_dp_gloo.py; the LocalEnhancer's generator gradients travel as ONE bucket, only the
+    GlobalGenerator has a staged backward -- DESIGN.md 5)."""
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    o = _opt(netG="local", n_downsample_global=4, n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=True, mask=True)
+    m = create_model(o)
+    assert sum(p.numel() for p in m.netG.parameters()) == 156_050_690
+    T = 255 * 512
+    gen = torch.Generator().manual_seed(4)
+    hr = (0.1 * torch.randn(32, T, generator=gen)).cuda()
+    lr = (0.1 * torch.randn(32, T, generator=gen)).cuda()
+    w0 = m.optimizer_G.flat_p.clone()
+    for _ in range(4):                                             # 2 eager steps, capture, one more replay
+        ld = m.train_step_graphed(lr, hr)
+    torch.cuda.synchronize()
+    assert m._graph_state["graphs"] is not None
+    for k in ("G_GAN", "G_GAN_Feat", "D_real", "D_fake"):
+        assert np.isfinite(float(ld[k])) and float(ld[k]) > 0, (k, float(ld[k]))
+    for opt_ in (m.optimizer_G, m.optimizer_D):
+        assert torch.isfinite(opt_.flat_p).all()
+        for p_, off in zip(opt_._params, opt_._offs):
+            seg = opt_.flat_g[off:off + p_.numel()]
+            assert torch.isfinite(seg).all() and float(seg.abs().max()) > 0, (tuple(p_.shape), off)
+    assert float((m.optimizer_G.flat_p - w0).abs().max()) > 0
