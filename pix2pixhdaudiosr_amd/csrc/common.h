@@ -28,6 +28,7 @@ inline int check_launch(const char* what) {
 
 // tuning override (p2phd_set_option "mdct_generic"): 1 = always the generic LDS kernels of mdct.hip
 extern int g_opt_mdct_generic;
+extern int g_opt_mdct_iters;     // tiles per workgroup of the fast forward transform (0 = heuristic)
 // mdct_fast.hip: register-resident kernels for hop = n_fft/2, win = n_fft, n_fft in {1024, 2048}
 bool mdct4_fast_ok(int n_fft, int hop, int win, int64_t row_len, int64_t start_pad, const void* a, const void* b);
 int mdct4_fast_fwd(const float* x, int64_t B, int64_t T, int n_fft, const float* window, const float* tables,

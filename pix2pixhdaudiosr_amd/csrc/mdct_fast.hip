@@ -142,7 +142,8 @@ template <int R>
 __global__ __launch_bounds__(64 * kWaves) void mdct4_fast_fwd_kernel(const float* __restrict__ x, long T,
                                                                       const float* __restrict__ window,
                                                                       const float* __restrict__ tables, long start_pad, long F,
-                                                                      float scale, float* __restrict__ out, int n_tiles) {
+                                                                      float scale, float* __restrict__ out, int n_tiles,
+                                                                      int wg_tiles, int iters) {
   constexpr int N = 256 * R, M = N / 2;
   constexpr int SEG = (kFramesPerWave + 1) * M;                // floats staged per wave
   extern __shared__ float4 smem_raw[];
@@ -150,14 +151,36 @@ __global__ __launch_bounds__(64 * kWaves) void mdct4_fast_fwd_kernel(const float
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* seg = reinterpret_cast<float*>(smem_raw) + (size_t)wave * SEG;
 
-  const long b = blockIdx.x / n_tiles;
-  const long t0 = (long)(blockIdx.x % n_tiles) * kFramesPerWG + wave * kFramesPerWave;
-  if (t0 >= F) return;                                         // no workgroup barrier anywhere: a wave may leave
+  // A workgroup walks `iters` consecutive 8-frame tiles of one row (round 3): the per-lane constants below (twiddles,
+  // rotations, window values: ~30 dependent loads) are fetched once per wave instead of once per tile, and a grid of more
+  // than one resident round (4 workgroups per CU: 1024) collapses into one.
+  const long b = blockIdx.x / wg_tiles;
+  const long tile0 = (long)(blockIdx.x % wg_tiles) * iters;
+  const float* xb = x + b * T;
+  Consts<R> cs;
+  load_consts<R>(cs, tables, lane);
+  // window values of the lane's fold: points r < R/2 use positions (3M/2-1-2i, 3M/2+2i, M/2-1-2i, M/2+2i),
+  // points r >= R/2 use (2i-M/2, 3M/2-1-2i, M/2+2i, 5M/2-1-2i).  Positions are one add from the lane index and are
+  // recomputed where they are used (kept in registers they cost a wave per SIMD); the window values stay resident.
+  auto fold_pos = [&](int r, int e) -> int {
+    const int i2 = 2 * (lane + 64 * r);
+    if (r < R / 2) return e == 0 ? 3 * (M / 2) - 1 - i2 : (e == 1 ? 3 * (M / 2) + i2 : (e == 2 ? M / 2 - 1 - i2 : M / 2 + i2));
+    return e == 0 ? i2 - M / 2 : (e == 1 ? 3 * (M / 2) - 1 - i2 : (e == 2 ? M / 2 + i2 : 5 * (M / 2) - 1 - i2));
+  };
+  float wv[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) wv[r][e] = window[fold_pos(r, e)];
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+  const long tile = tile0 + it;
+  const long t0 = tile * kFramesPerWG + wave * kFramesPerWave;
+  if (tile >= n_tiles || t0 >= F) break;                       // no workgroup barrier anywhere: a wave may leave
   const int nf = (int)min((long)kFramesPerWave, F - t0);
 
   // stage the wave's signal span: coalesced float4, zeros outside [0, T) (T, start_pad, hop are multiples of 4)
   const long p0 = t0 * M - start_pad;
-  const float* xb = x + b * T;
   float4 ld[SEG / 256];
 #pragma unroll
   for (int c = 0; c < SEG / 256; ++c) {
@@ -165,23 +188,6 @@ __global__ __launch_bounds__(64 * kWaves) void mdct4_fast_fwd_kernel(const float
     const bool ok = idx >= 0 && idx + 3 < T;
     ld[c] = *reinterpret_cast<const float4*>(xb + (ok ? idx : 0));
     if (!ok) ld[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-  Consts<R> cs;
-  load_consts<R>(cs, tables, lane);
-  // window values of the lane's fold: points r < R/2 use positions (3M/2-1-2i, 3M/2+2i, M/2-1-2i, M/2+2i),
-  // points r >= R/2 use (2i-M/2, 3M/2-1-2i, M/2+2i, 5M/2-1-2i)
-  int pos[R][4];
-  float wv[R][4];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int i2 = 2 * (lane + 64 * r);
-    if (r < R / 2) {
-      pos[r][0] = 3 * (M / 2) - 1 - i2; pos[r][1] = 3 * (M / 2) + i2; pos[r][2] = M / 2 - 1 - i2; pos[r][3] = M / 2 + i2;
-    } else {
-      pos[r][0] = i2 - M / 2; pos[r][1] = 3 * (M / 2) - 1 - i2; pos[r][2] = M / 2 + i2; pos[r][3] = 5 * (M / 2) - 1 - i2;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) wv[r][e] = window[pos[r][e]];
   }
 #pragma unroll
   for (int c = 0; c < SEG / 256; ++c) store4(seg, 4 * (lane + 64 * c), ld[c]);
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(64 * kWaves) void mdct4_fast_fwd_kernel(const float
     for (int r = 0; r < R; ++r) {
       float u[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) u[e] = seg[sf(f * M + pos[r][e])] * wv[r][e];
+      for (int e = 0; e < 4; ++e) u[e] = seg[sf(f * M + fold_pos(r, e))] * wv[r][e];
       const float2 z = r < R / 2 ? make_float2(-u[0] - u[1], u[2] - u[3]) : make_float2(u[0] - u[1], -u[2] - u[3]);
       v[f][r] = cmul(z, cs.rot[r]);
     }
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(64 * kWaves) void mdct4_fast_fwd_kernel(const float
       wave_sync();
     }
   }
+  }                                                            // tiles of this workgroup
 }
 
 // ------------------------------------------------------------------------------------------
@@ -341,8 +348,15 @@ int launch_fwd(const float* x, int64_t B, int64_t T, const float* window, const 
   const size_t lds = sizeof(float) * (size_t)kWaves * (kFramesPerWave + 1) * M;
   auto kern = mdct4_fast_fwd_kernel<R>;
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(B * n_tiles)), dim3(64 * kWaves), lds, st, x, (long)T, window, tables, (long)start_pad,
-                     (long)n_frames, scale, out, (int)n_tiles);
+  // tiles per workgroup: as many as keep the grid within one resident round (4 workgroups per CU by registers), at most 4
+  // (resident workgroups: 3 per CU for n_fft 1024 -- 148 VGPRs --, 2 for n_fft 2048; p2phd_set_option("mdct_iters", n) forces n)
+  const int64_t resident = (R == 4 ? 3 : 2) * 256;
+  int iters = 1;
+  while (iters < 4 && B * p2phd::cdiv(n_tiles, iters) > resident) ++iters;
+  if (p2phd::g_opt_mdct_iters > 0) iters = p2phd::g_opt_mdct_iters;
+  const int64_t wg_tiles = p2phd::cdiv(n_tiles, iters);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(B * wg_tiles)), dim3(64 * kWaves), lds, st, x, (long)T, window, tables, (long)start_pad,
+                     (long)n_frames, scale, out, (int)n_tiles, (int)wg_tiles, iters);
   return p2phd::check_launch("mdct4_fwd(fast)");
 }
 
