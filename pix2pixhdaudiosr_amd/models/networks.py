@@ -223,6 +223,20 @@ def _run(steps, x, residual_last=None, cuts=None, cut_after=(), first_exclusive=
     return x
 
 
+def _balanced_cuts(counts, n_buckets):
+    """Indices j such that a cut AFTER step j splits a chain with `counts` parameters per step into `n_buckets` runs of
+    roughly equal size, assigned from the end (the backward's order)."""
+    cut_after, acc, remaining, left = [], 0, sum(counts), n_buckets
+    for j in range(len(counts) - 1, 0, -1):
+        acc += counts[j]
+        if left > 1 and acc >= remaining / left:              # this bucket holds its share of what is still unassigned
+            cut_after.append(j - 1)
+            remaining -= acc
+            left -= 1
+            acc = 0
+    return sorted(set(cut_after))
+
+
 def _step_params(step):
     if isinstance(step, _ResStep):
         return _step_params(step.a) + _step_params(step.b)
@@ -366,19 +380,9 @@ class GlobalGenerator(_HipNet):
         Returns (cut_after, first_param_index): step indices in execution order, and for every cut the index (into
         list(self.parameters())) of the first parameter of the step that follows it."""
         steps = self._steps('model')
-        counts = [sum(p.numel() for p in _step_params(s)) for s in steps]
-        total = sum(counts)
         if n_buckets <= 1 or len(steps) < 2:
             return [], []
-        cut_after, acc, remaining, left = [], 0, total, n_buckets
-        for j in range(len(steps) - 1, 0, -1):                # walk backwards: the backward's order
-            acc += counts[j]
-            if left > 1 and acc >= remaining / left:          # this bucket holds its share of what is still unassigned
-                cut_after.append(j - 1)
-                remaining -= acc
-                left -= 1
-                acc = 0
-        cut_after = sorted(set(cut_after))
+        cut_after = _balanced_cuts([sum(p.numel() for p in _step_params(s)) for s in steps], n_buckets)
         ids = [id(p) for p in self.parameters()]
         first = [ids.index(id(_step_params(steps[j + 1])[0])) for j in cut_after]
         return cut_after, first
@@ -419,11 +423,36 @@ class LocalEnhancer(_HipNet):
 
         self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
 
-    def forward_physical(self, x):
+    def bucket_plan(self, n_buckets):
+        """Staged backward for the data-parallel exchange (round 3; one local enhancer).  The backward graph is a tail
+        (model1_2), then TWO parallel branches behind the sum `model1_1(x) + model(pool(x))`: the enhancer's head and the
+        global chain.  Parameters are registered global chain first, then model1_1, then model1_2, so everything outside
+        the global chain is one contiguous tail of the flat gradient buffer: the first cut is always the global chain's
+        OUTPUT (bucket 0 = the enhancer's own layers, `staged_head_anchors` makes the head stage run the parallel branch
+        too), the remaining n_buckets - 1 buckets balance the global chain like GlobalGenerator.bucket_plan."""
+        steps = self._steps('model')
+        if n_buckets <= 1 or self.n_local_enhancers != 1 or len(steps) < 2:
+            return [], []
+        counts = [sum(p.numel() for p in _step_params(s)) for s in steps]
+        inner = _balanced_cuts(counts, n_buckets - 1) if n_buckets > 2 else []
+        cut_after = sorted(set(inner + [len(steps) - 1]))
+        ids = [id(p) for p in self.parameters()]
+        first = []
+        for j in cut_after:
+            nxt = _step_params(steps[j + 1])[0] if j + 1 < len(steps) else _step_params(_flat_conv_steps(self._steps('model1_1'))[0])[0]
+            first.append(ids.index(id(nxt)))
+        return cut_after, first
+
+    def staged_head_anchors(self):
+        """Tensors the head stage of a staged backward must ALSO differentiate, so that autograd runs the branch that is
+        parallel to the last cut (the enhancer's head, whose weight gradients land in bucket 0): its first conv weight."""
+        return [_flat_conv_steps(self._steps('model1_1'))[0].conv.weight]
+
+    def forward_physical(self, x, cuts=None, cut_after=()):
         pyramid = [x]
         for _ in range(self.n_local_enhancers):
             pyramid.append(_ops.avgpool(pyramid[-1], self.input_nc))
-        out = _run(self._steps('model'), pyramid[-1])
+        out = _run(self._steps('model'), pyramid[-1], cuts=cuts, cut_after=cut_after)
         for n in range(1, self.n_local_enhancers + 1):
             xi = pyramid[self.n_local_enhancers - n]
             # model{n}_1(x_i) + out : the sum rides on the last InstanceNorm+ReLU launch of the head

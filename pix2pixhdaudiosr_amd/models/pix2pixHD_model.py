@@ -457,9 +457,13 @@ class Pix2PixHDModel(BaseModel):
         state = {}
         stages = []
 
+        anchors = list(getattr(self.netG, 'staged_head_anchors', lambda: [])())
+
         def head():
             with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream(), self._fake_half():
-                (state['g'],) = torch.autograd.grad(loss_G, [cuts[-1]], retain_graph=True)
+                # (anchors: parameters of a branch parallel to the last cut -- the LocalEnhancer's head; their gradient
+                # arrives in the flat buffer like every other one, autograd itself gets None for them)
+                state['g'] = torch.autograd.grad(loss_G, [cuts[-1]] + anchors, retain_graph=True, allow_unused=True)[0]
         stages.append((head, (offs[-1], total)))
         for i in range(len(cuts) - 2, -1, -1):
             def mid(i=i):

@@ -380,12 +380,13 @@ def test_configs3_per_rank_step_local_enhancer_bf16_batch32():
     """BASELINE configs[3] is configs[2]'s generator (GEN_VCTK_G3L2_48ngf as opt.txt reads it: LocalEnhancer ngf 48, 4 global
     down-samplings, 3 global blocks, 1 local enhancer, 2 local blocks) in bf16 at per-GPU batch 32 on 8 GPUs.  What one rank
     runs -- the graphed bf16 step of that model at B = 32, 512x256 -- runs here on one GPU (the exchange itself:
-    tests/test_gpu_dp.py, test_dp_gloo.py; the LocalEnhancer's generator gradients travel as ONE bucket, only the
-    GlobalGenerator has a staged backward -- DESIGN.md 5)."""
+    tests/test_gpu_dp.py, test_dp_gloo.py; the LocalEnhancer's 4-stage backward: test_gpu_model.py), with the staged
+    generator backward the data-parallel step uses (grad_buckets = 4)."""
     from pix2pixhdaudiosr_amd.models.models import create_model
-    o = _opt(netG="local", n_downsample_global=4, n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=True, mask=True)
+    o = _opt(netG="local", n_downsample_global=4, n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=True, mask=True, grad_buckets=4)
     m = create_model(o)
     assert sum(p.numel() for p in m.netG.parameters()) == 156_050_690
+    assert m._bucket_plan()[0] == 4 and len(m._bucket_plan()[1]) == 3
     T = 255 * 512
     gen = torch.Generator().manual_seed(4)
     hr = (0.1 * torch.randn(32, T, generator=gen)).cuda()

@@ -486,6 +486,39 @@ def test_staged_backward_equals_single_backward(golden_model):
     assert four.optimizer_G.bucket_log == bk
 
 
+def test_local_enhancer_staged_backward_equals_single_backward():
+    """Round 3: the LocalEnhancer (configs[2] / [3]) has a staged backward too.  Its backward graph forks behind the sum
+    `model1_1(x) + model(pool(x))`; the first cut is the global chain's output, the head stage also runs the enhancer's
+    head (LocalEnhancer.staged_head_anchors), and the buckets are contiguous ranges of the flat buffer covering it exactly
+    once.  Same kernels in the same order as the single backward: identical gradients; also replayed from the graphs."""
+    from pix2pixhdaudiosr_amd.models.models import create_model
+    from pix2pixhdaudiosr_amd import _ops
+    kw = dict(netG="local", ngf=8, n_downsample_global=2, n_blocks_global=2, n_local_enhancers=1, n_blocks_local=1, mask=False)
+    one, four = create_model(make_opt(**kw)), create_model(make_opt(grad_buckets=4, **kw))
+    four.netG.load_state_dict(one.netG.state_dict()); four.netD.load_state_dict(one.netD.state_dict())
+    _ops.bump_weight_epoch()
+    n, cut_after, offs = four._bucket_plan()
+    assert n == 4 and len(cut_after) == 3 and offs == sorted(offs) and 0 < offs[0] and offs[-1] < four.optimizer_G._total
+    assert cut_after[-1] == len(four.netG._steps('model')) - 1       # the last cut = the global chain's output
+    gen = torch.Generator().manual_seed(5)
+    T = 15 * 32
+    lr, hr = (0.1 * torch.randn(2, T, generator=gen)).cuda(), (0.1 * torch.randn(2, T, generator=gen)).cuda()
+    la = one.train_step(lr, hr)
+    lb = four.train_step(lr, hr)
+    bk = four.optimizer_G.bucket_log
+    assert len(bk) == 4 and bk[0][1] == four.optimizer_G._total and bk[-1][0] == 0 and all(bk[i][0] == bk[i + 1][1] for i in range(3)), bk
+    for k in la:
+        assert abs(float(la[k]) - float(lb[k])) <= 1e-6 * max(1.0, abs(float(la[k]))), k
+    assert _grad_diff(one, four, "optimizer_G") < 1e-6 and _grad_diff(one, four, "optimizer_D") < 1e-6
+    # every generator tensor received its gradient (the enhancer's head is the branch a naive staging would skip)
+    for (k, p), off in zip(four.netG.named_parameters(), four.optimizer_G._offs):
+        if k.endswith(".weight"):
+            assert float(four.optimizer_G.flat_g[off:off + p.numel()].abs().max()) > 0, k
+    for _ in range(4):
+        four.train_step_graphed(lr, hr)
+    assert len(four._graph_state['graphs'][0]) == 4
+
+
 def test_weight_gradients_on_the_side_stream(golden_model, monkeypatch):
     """P2PHD_WGRAD_STREAM=1: the weight-gradient kernels of the model's backward stages run on a second stream (their
     operands kept alive until the join).  Same kernels on the same data: the result must agree with the single-stream
