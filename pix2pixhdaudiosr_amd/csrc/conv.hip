@@ -448,7 +448,13 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
 #endif
       __builtin_amdgcn_sched_barrier(0);
+#ifdef P2PHD_MFMAPRIO
+      __builtin_amdgcn_s_setprio(1);                             // (guide T5: priority around the MFMA cluster; measured null here)
+#endif
       mfma_rest(buf, MR * NR > 1 ? 2 : 1);
+#ifdef P2PHD_MFMAPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef P2PHD_PROBE
