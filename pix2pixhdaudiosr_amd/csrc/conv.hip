@@ -18,9 +18,10 @@
 // before the MFMAs of the current one; LDS rows are 128 B with a 16-byte-chunk XOR swizzle ((row>>1)&7), applied
 // to the per-lane SOURCE address because the LDS side of a direct load is lane-linear, so the ds_read_b128
 // fragment reads of v_mfma_f32_32x32x16_bf16 are bank-conflict free.  fp32 mode (parity runs) uses the exact
-// v_mfma_f32_32x32x2_f32 on the same tiles.  The epilogue adds bias, accumulates the per-(n,channel) sum and
-// sum of squares InstanceNorm needs (wave reduction + one float atomic per wave and channel), applies an
-// optional activation, stages the tile in LDS and writes whole 16-byte pieces of NHWC rows.
+// v_mfma_f32_32x32x2_f32 on the same tiles.  The epilogue adds bias, leaves the per-wave (sum, M2) partials InstanceNorm
+// needs in the wave's own slot of a table (merged with Chan's update by a small kernel: no float atomics), applies an
+// optional activation, stages the tile in LDS and writes whole 16-byte pieces of NHWC rows.  Round 3: the launch is a 1-D
+// grid over tiles whose last, almost empty round is cut along K (split-K tail, launch_gconv_cfg).
 //
 // The weight gradient is a second kernel: M = out channels, N = taps x in channels, reduction over pixels.
 // Both operands then have the reduction index as the slow LDS dimension; bf16 fragments are fetched with the

@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
     }
   }
   if (db != nullptr) {
+    // float atomics on purpose: db is the bias gradient of a conv IN FRONT of this InstanceNorm, whose exact value is 0
+    // (the normalisation removes per-channel constants) -- both this sum and the reference's hold rounding noise only,
+    // so a fixed summation order (fold_arrive_last: a tail of one workgroup per launch) would buy nothing here
 #pragma unroll
     for (int k = 0; k < EPP; ++k) atomicAdd(&s_db[pc * EPP + k], bsum[k]);     // LDS atomics
     __syncthreads();
