@@ -1072,6 +1072,22 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MI * NI > 1) mfma_one(buf, 1 / NI, 1 % NI);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef P2PHD_STAGGER
+        if (sub == 0 && pend) {                                   // (see gconv_kernel: waves 4-7 issue their pieces one sub-step later)
+#pragma unroll
+          for (int j = 0; j < NLOADS; ++j) issue_piece(pend_slot, j);
+          pend = false;
+        }
+        if (sub == NSUB - 1 && issue_new) {
+          prepare();
+          if (wave < 4) {
+#pragma unroll
+            for (int j = 0; j < NLOADS; ++j) issue_piece(cur, j);
+          } else {
+            pend = true; pend_slot = cur;
+          }
+        }
+#else
         if (sub == 0 && pend) {
 #pragma unroll
           for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, j);
@@ -1083,6 +1099,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
           for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, j);
           pend = true; pend_slot = cur;
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
