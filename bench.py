@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 FRAMES = 256                      # spectrogram frames per sample at 512x256
 BF16_DENSE_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FP8_DENSE_PEAK_TFLOPS = 5000.0    # ~5 PF dense fp8 (block-scaled f8f6f4 MFMA)
 M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd4 nb9 @512x256 (SURVEY 8a probe)
 M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
 
@@ -480,13 +481,12 @@ def main():
                            "launches_timed": "forward launches only (gather pad_mode 1); the same-shaped input-gradient launches: dgrad_launch_us",
                            "dgrad_launch_us": None if sec_dgrad is None else sec_dgrad * 1e6}
         if a.fp8 and world == 1:
-            # the probed launches are the e4m3 forward of the trunk on the NON-scaled v_mfma_f32_32x32x16_fp8_fp8, which issues at
-            # the cycles of the bf16 form (MI355X_MICROARCH.md, matrix-core table): its ceiling is the bf16 peak, not the 5 PF
-            # of the block-scaled f8f6f4 instructions -- the launch is priced against 2.5 PF; the recorded HBM traffic (taken on
-            # the bf16 kernel) does not apply
-            out["roofline"].update({"peak": BF16_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS,
+            # the probed launches are the e4m3 forward of the trunk on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit
+            # e8m0 scales; twice the bf16 rate, MI355X_MICROARCH.md matrix-core table): priced against the 5 PF dense fp8 peak;
+            # the recorded HBM traffic (taken on the bf16 kernel) does not apply
+            out["roofline"].update({"peak": FP8_DENSE_PEAK_TFLOPS, "frac": flops / sec / 1e12 / FP8_DENSE_PEAK_TFLOPS,
                                     "traffic": None, "traffic_source": None,
-                                    "peak_note": "non-scaled fp8 MFMA runs at the bf16 issue rate: priced against the bf16 dense peak",
+                                    "peak_note": "block-scaled e4m3 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): priced against the 5 PF dense fp8 peak",
                                     "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
         if world == 1 and not a.no_probes:
             try:

@@ -157,7 +157,8 @@ int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const void* packed_f
                    void* y, float* stats, void* workspace, void* stream);
 
 /* fp8 forward of the wide stride-1 layers (BASELINE configs[4]: bf16 + fp8 MFMA conv weights; the reference analogue is its
- * AMP path, train.py:62-67,148-149).  Operands are OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8, accumulation fp32, outputs bf16;
+ * AMP path, train.py:62-67,148-149).  Operands are OCP e4m3 on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit e8m0 block scales: the layer's one
+ * scale is applied in the epilogue; twice the bf16 MFMA rate), accumulation fp32, outputs bf16;
  * fp32 master weights, the bf16 activations and the whole backward pass are unchanged.
  *   p2phd_conv_fp8_eligible   : 1 if the layer can run this way (Conv2d, stride 1, C %% 16 == 0, R*S*C %% 128 == 0, desc.dtype BF16)
  *   p2phd_conv_fp8_pack_weights: per-layer scale = max|w| / 448 found on the device (no host sync), weights quantised into

@@ -262,24 +262,22 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const int lr = lane & 31, lh = lane >> 5;
   // Fragment reads are inline-asm ds_read_b128: hipcc cannot prove a C++ LDS read independent of the LDS-DMA still in
   // flight and would drain it (s_waitcnt vmcnt(0)) in front of every K step; the waits here are counted by hand.
-  // byte offset inside a stage of the fragment of k-slab ks: row * 128 + (((2 ks + lh) ^ ((row >> 1) & 7)) << 4)
-  unsigned fa[MR][4], fb[NR][4];
+  // byte offset inside a stage of the fragment of k-step ks: row * 128 + (((2 ks + lh) ^ ((row >> 1) & 7)) << 4)
+  //   = (offset of k-step 0) ^ (ks << 5): one address register per fragment row, the k-step is an XOR at the use
+  unsigned fa[MR], fb[NR];
   {
-    const unsigned sbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stages;
 #pragma unroll
     for (int i = 0; i < MR; ++i) {
       const int row = wm * (MR * 32) + i * 32 + lr;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[i][ks] = sbase + row * kRowBytes + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4);
+      fa[i] = row * kRowBytes + ((lh ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
       const int row = wn * (NR * 32) + j * 32 + lr;
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        fb[j][ks] = sbase + BM * kRowBytes + row * kRowBytes + (((2 * ks + lh) ^ ((row >> 1) & 7)) << 4);
+      fb[j] = BM * kRowBytes + row * kRowBytes + ((lh ^ ((row >> 1) & 7)) << 4);
     }
   }
+  const unsigned frag_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)stages;
 
   // ---- main loop -------------------------------------------------------------------------------------------
   // NSTAGE-slot LDS ring; tile t lives in slot t % NSTAGE.  ONE workgroup barrier per K slab, placed in front of the
@@ -291,31 +289,39 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   //   * this slab's slot is free: tile s + NSTAGE is issued into it at once (half now, half one k-step later), giving
   //     the DMA more than a full slab of MFMA work to land, even on the 2-slot ring of the 256-wide tiles.
   // The later tiles stay in flight ACROSS the barrier (raw s_barrier; __syncthreads() would drain them).
-  uint4 af[2][MR], bfr[2][NR];
-  auto read_frags = [&](unsigned so, int ks, int buf) {
+  // fragment buffers: two (ping-pong over the k-steps), or one per k-step for the e4m3 operands, whose block-scaled MFMA
+  // consumes the fragments of TWO k-steps at once (see mfma_one)
+  constexpr int NFB = sizeof(T) == 1 ? 4 : 2;
+  uint4 af[NFB][MR], bfr[NFB][NR];
+  auto read_frags = [&](unsigned so_, int ks, int buf) {
+    const unsigned so = so_ + frag_base;
 #ifdef P2PHD_ABL_NOLDSREAD
 #pragma unroll
-    for (int i = 0; i < MR; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(af[buf][i].x) : "v"(fa[i][ks] + so));
+    for (int i = 0; i < MR; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(af[buf][i].x) : "v"((fa[i] ^ (unsigned)(ks << 5)) + so));
 #pragma unroll
-    for (int j = 0; j < NR; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bfr[buf][j].x) : "v"(fb[j][ks] + so));
+    for (int j = 0; j < NR; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bfr[buf][j].x) : "v"((fb[j] ^ (unsigned)(ks << 5)) + so));
 #else
 #pragma unroll
-    for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"(fa[i][ks] + so));
+    for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"((fa[i] ^ (unsigned)(ks << 5)) + so));
 #pragma unroll
-    for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"(fb[j][ks] + so));
+    for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"((fb[j] ^ (unsigned)(ks << 5)) + so));
 #endif
   };
   // One MFMA cluster (MR x NR tiles, one k-step); `h0` / `h1` are issued in the shadow of its first / second MFMA
   // (fragment reads, LDS-DMA issue), so the matrix pipe already has work when the wave turns to them.
   auto mfma_one = [&](int buf, int i, int j) {
     if constexpr (sizeof(T) == 1) {
-      // a 16-byte fragment holds 16 e4m3 values: two MFMAs of K = 16 (any K permutation is fine, A and B share it), i.e.
-      // half the LDS fragment traffic per MAC of the bf16 form
+#ifdef P2PHD_FP8_NOSCALE
+      // (round-2 form: two non-scaled K = 16 MFMAs per 16-byte fragment, the bf16 issue rate)
       const uint4 av = af[buf][i], bw = bfr[buf][j];          // (composed from the dwords: pointer arithmetic on the fragment
       const long a0 = (long)(((unsigned long)av.y << 32) | av.x), a1 = (long)(((unsigned long)av.w << 32) | av.z);   // arrays puts them in scratch)
       const long b0 = (long)(((unsigned long)bw.y << 32) | bw.x), b1 = (long)(((unsigned long)bw.w << 32) | bw.z);
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[i][j], 0, 0, 0);
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[i][j], 0, 0, 0);
+#else
+      // (block-scaled form: see mfma8 below)
+      (void)buf; (void)i; (void)j;
+#endif
     } else if constexpr (sizeof(T) == 2) {
 #ifdef P2PHD_ABL_NOMFMA
       asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
@@ -339,6 +345,45 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[e], b4[e], acc[i][j], 0, 0, 0);
     }
   };
+  // Block-scaled MFMA of the e4m3 operands (round 3): v_mfma_scale_f32_32x32x64_f8f6f4 runs at TWICE the bf16 rate (the
+  // non-scaled 32x32x16_fp8_fp8 runs AT the bf16 rate).  It takes 32 bytes of K per lane: the 16-byte fragments of two
+  // consecutive k-steps side by side (any K permutation is fine as long as A and B share it).  Scales: e8m0 = 127 (1.0)
+  // for every 32-element block -- the layer's scale is applied once in the epilogue, as before, so the numbers are those
+  // of the non-scaled form.  A pair of k-steps (2q, 2q+1) is complete at the odd k-step, where its MR x NR MFMAs go out
+  // (H1 = all of them).  -DP2PHD_FP8_SPREAD issues only the first half there and the second half at the following even
+  // k-step (for the pair (2,3): k-step 0 of the NEXT slab; flushed after the loop), so that every k-step has matrix work
+  // to hide its fragment reads behind: measured SLOWER (trunk 108 vs 103 us, cfg5 trunk 183 vs 172 us; 256 VGPRs against
+  // 239) -- the two waves of a SIMD already fill each other's gaps.  Position p of k-step ks:
+#ifdef P2PHD_FP8_SPREAD
+  constexpr int NT8 = MR * NR, H1 = (NT8 + 1) / 2;
+#else
+  constexpr int NT8 = MR * NR, H1 = NT8;
+#endif
+  auto mfma8 = [&](int ks, int p) {
+    if constexpr (sizeof(T) == 1) {
+      const int idx = (ks & 1) ? p : H1 + p;
+      if (p < H1 && idx < NT8) {
+        const int lo = (ks & 1) ? ks - 1 : ((ks + 2) & 3), hi = lo + 1;
+        const int i = idx / NR, j = idx % NR;
+        typedef __attribute__((ext_vector_type(8))) int i32x8;
+        const uint4 a0 = af[lo][i], a1 = af[hi][i], b0 = bfr[lo][j], b1 = bfr[hi][j];
+        const i32x8 av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+        const i32x8 bv = {(int)b0.x, (int)b0.y, (int)b0.z, (int)b0.w, (int)b1.x, (int)b1.y, (int)b1.z, (int)b1.w};
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bv, acc[i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    }
+  };
+#ifdef P2PHD_FP8_NOSCALE
+  constexpr bool kScaled = false;
+#else
+  constexpr bool kScaled = sizeof(T) == 1;
+#endif
+  if constexpr (kScaled) {                                     // (the first slab's k-step 0 multiplies zeros)
+#pragma unroll
+    for (int i = 0; i < MR; ++i) af[2][i] = af[3][i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) bfr[2][j] = bfr[3][j] = make_uint4(0, 0, 0, 0);
+  }
   // the MFMAs of a cluster after its first `skip`
   auto mfma_rest = [&](int buf, int skip) {
 #pragma unroll
@@ -388,7 +433,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     const bool issue_new = s + NSTAGE < nsteps;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int buf = ks & 1;
+      const int buf = sizeof(T) == 1 ? ks : (ks & 1);
+      const int nbuf = sizeof(T) == 1 ? ((ks + 1) & 3) : (buf ^ 1);   // where the next k-step's fragments go
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (ks == 3 && has_next) {
         // slab boundary: every LDS read of this slot is complete; own pieces of the next tile must have landed
@@ -407,12 +453,12 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_one(buf, 0, 0);
+      if constexpr (kScaled) mfma8(ks, 0); else mfma_one(buf, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (ks < 3) read_frags(so, ks + 1, buf ^ 1);
+      if (ks < 3) read_frags(so, ks + 1, nbuf);
       else if (has_next) read_frags((unsigned)(nslot * STAGE), 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (MR * NR > 1) mfma_one(buf, 1 / NR, 1 % NR);
+      if constexpr (kScaled) mfma8(ks, 1); else if constexpr (MR * NR > 1) mfma_one(buf, 1 / NR, 1 % NR);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef P2PHD_ABL_NODMA
 #ifdef P2PHD_STAGGER
@@ -452,7 +498,12 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_MFMAPRIO
       __builtin_amdgcn_s_setprio(1);                             // (guide T5: priority around the MFMA cluster; measured null here)
 #endif
-      mfma_rest(buf, MR * NR > 1 ? 2 : 1);
+      if constexpr (kScaled) {
+#pragma unroll
+        for (int p = 2; p < H1; ++p) mfma8(ks, p);
+      } else {
+        mfma_rest(buf, MR * NR > 1 ? 2 : 1);
+      }
 #ifdef P2PHD_MFMAPRIO
       __builtin_amdgcn_s_setprio(0);
 #endif
@@ -462,6 +513,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     pr_comp += __builtin_readcyclecounter() - pt0;
 #endif
     cur = nslot;
+  }
+  if constexpr (kScaled) {                                     // second half of the last slab's pair (2,3)
+#pragma unroll
+    for (int p = 0; p < H1; ++p) mfma8(0, p);
   }
 #ifdef P2PHD_PROBE
   const unsigned long long pr_t2 = __builtin_readcyclecounter();
