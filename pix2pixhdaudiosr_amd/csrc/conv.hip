@@ -766,29 +766,49 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       return;
     }
   }
-  for (int q = tid; q < BM * CPR; q += NT) {
-    const int row = q / CPR, pc = q - row * CPR;
-    int k = n0 + pc * EPPO;
-    const int2 ri = rinfo[row];
-    if (ri.x < 0 || k >= n_extent) continue;
-    const int nn = ri.x;
-    int ho = ri.y >> 16, wo = ri.y & 0xFFFF;
-    if (cls_cp > 0) {                                          // class (pi,pj) -> output pixel (2 ho + pi, 2 wo + pj)
-      const int cls = (k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp);
-      k -= cls * cls_cp;
-      ho = 2 * ho + (cls >> 1); wo = 2 * wo + (cls & 1);
-      if (ho >= Hout || wo >= Wout) continue;
-    }
-    const size_t opix = ((size_t)nn * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo);
-    uint4 v = *reinterpret_cast<const uint4*>(ct + row * CROW + pc * 16);
-    if (addend != nullptr) {
-      const uint4 a = *reinterpret_cast<const uint4*>(addend + opix * Cp_out + k);
-      TO* vv = reinterpret_cast<TO*>(&v);
-      const TO* aa = reinterpret_cast<const TO*>(&a);
+  // U pieces per thread at a time: their row records, staged pieces (and addends) are all requested before the first one
+  // is used -- one piece per iteration costs two LDS round trips and a branch per 16 bytes stored (2 waves per SIMD: nobody
+  // to hide them behind)
+  {
+    constexpr int TOTAL = BM * CPR, U = 4;
+    for (int q0 = tid; q0 < TOTAL; q0 += NT * U) {
+      int2 ri[U];
+      int rowu[U], pcu[U];
 #pragma unroll
-      for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) + to_f(aa[e]));
+      for (int u = 0; u < U; ++u) {
+        const int q = min(q0 + u * NT, TOTAL - 1);
+        rowu[u] = q / CPR; pcu[u] = q - rowu[u] * CPR;
+        ri[u] = rinfo[rowu[u]];
+      }
+      uint4 v[U], av[U];
+      size_t off[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        int k = n0 + pcu[u] * EPPO;
+        ok[u] = q0 + u * NT < TOTAL && ri[u].x >= 0 && k < n_extent;
+        int ho = ri[u].y >> 16, wo = ri[u].y & 0xFFFF;
+        if (cls_cp > 0) {                                        // class (pi,pj) -> output pixel (2 ho + pi, 2 wo + pj)
+          const int cls = (k >= cls_cp) + (k >= 2 * cls_cp) + (k >= 3 * cls_cp);
+          k -= cls * cls_cp;
+          ho = 2 * ho + (cls >> 1); wo = 2 * wo + (cls & 1);
+          ok[u] = ok[u] && ho < Hout && wo < Wout;
+        }
+        off[u] = ok[u] ? (((size_t)ri[u].x * Hout + (ho * ohm + oho)) * Wout + (wo * owm + owo)) * Cp_out + k : 0;   // clamped: always loadable
+        v[u] = *reinterpret_cast<const uint4*>(ct + rowu[u] * CROW + pcu[u] * 16);
+        if (addend != nullptr) av[u] = *reinterpret_cast<const uint4*>(addend + off[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (addend != nullptr) {
+          TO* vv = reinterpret_cast<TO*>(&v[u]);
+          const TO* aa = reinterpret_cast<const TO*>(&av[u]);
+#pragma unroll
+          for (int e = 0; e < EPPO; ++e) vv[e] = from_f<TO>(to_f(vv[e]) + to_f(aa[e]));
+        }
+        if (ok[u]) *reinterpret_cast<uint4*>(out + off[u]) = v[u];
+      }
     }
-    *reinterpret_cast<uint4*>(out + opix * Cp_out + k) = v;
   }
 #ifdef P2PHD_PROBE
 #ifdef P2PHD_PROBE_DRAIN
@@ -1870,7 +1890,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   const bool fits_huge = sizeof(T) == 2 && 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
   bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
   if (d.bs_out != nullptr || d.as_x != nullptr) huge = false;   // (the 128-accumulator tile has no fused store loop)
-  const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds;
+  const bool fits3 = bn >= 64 && 3 * (256 + bn) * kRowBytes + tabb <= kLds && p2phd::g_opt_gconv_bm != 258;   // (258: experiments, 256 rows on the 2-slot ring)
   const bool fits2 = bn >= 64 && 2 * (256 + bn) * kRowBytes + tabb <= kLds && 256 * (bn * (long)sizeof(typename OutOf<T>::type) + 16) + tabb <= kLds;
   // short reductions (<= 4 K steps: the folded 2-channel layers, the 4-channel D input) are all prologue and epilogue:
   // keep the light 128-row kernel there, several of which fit on a CU and overlap each other's fixed costs
@@ -1878,7 +1898,7 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   bool big = (fits3 || fits2) && enough_px && !short_k && mt256 * ((k + bn - 1) / bn) >= 192;
   const int force = p2phd::g_opt_gconv_bm;
   if (force == 128) { big = false; huge = false; }
-  if (force == 256) { big = fits3 || fits2; huge = false; }
+  if (force == 256 || force == 258) { big = fits3 || fits2; huge = false; }
   if (force == 512) { huge = fits_huge && k > 128 && d.bs_out == nullptr && d.as_x == nullptr; }
   // 256 x 192 (8 waves of 64 x 96): when the 256 x 256 grid would leave CUs idle that a 192-wide N tile fills
   // (the residual trunk: 768 = 4 x 192 -> 64 x 4 = 256 workgroups instead of 64 x 3 = 192)

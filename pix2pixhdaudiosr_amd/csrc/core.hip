@@ -43,7 +43,7 @@ FoldScratch fold_scratch(int region) {
 }  // namespace p2phd
 
 extern "C" int p2phd_set_option(const char* name, int value) {
-  if (name && !strcmp(name, "gconv_bm") && (value == 0 || value == 128 || value == 192 || value == 256 || value == 512)) { p2phd::g_opt_gconv_bm = value; return P2PHD_OK; }
+  if (name && !strcmp(name, "gconv_bm") && (value == 0 || value == 128 || value == 192 || value == 256 || value == 258 || value == 512)) { p2phd::g_opt_gconv_bm = value; return P2PHD_OK; }
   if (name && !strcmp(name, "wgrad_tm") && (value == 0 || value == 128)) { p2phd::g_opt_wgrad_tm = value; return P2PHD_OK; }
   if (name && !strcmp(name, "reflect_generic") && (value == 0 || value == 1)) { p2phd::g_opt_reflect_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_iters") && value >= 0 && value <= 8) { p2phd::g_opt_mdct_iters = value; return P2PHD_OK; }
