@@ -7,6 +7,7 @@ C ABI, and ``torch.autograd.Function`` wrappers whose backward calls the HIP bac
 """
 import ctypes as C
 import contextlib
+import weakref
 
 import os
 import torch
@@ -409,6 +410,7 @@ class ConvSpec:
         self.transposed, self.opad = transposed, opad
         self.norm, self.act = norm, act
         self._packed = {}
+        self._pending = {}                                        # key -> event of a side-stream pack not yet waited for
         # fp8 forward (networks.enable_fp8): `fp8` = run this layer's forward on e4m3 operands when the input carries an
         # e4m3 twin; `emit_q8` = the InstanceNorm pass of this layer also writes the e4m3 twin of its output
         self.fp8 = False
@@ -449,13 +451,69 @@ class ConvSpec:
         stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
+            ev = self._pending.pop(key, None) if self._pending else None
+            if ev is not None:                                    # packed on the side stream of this step (prepack_weights)
+                torch.cuda.current_stream().wait_event(ev)
             return hit[1]
+        if _PREPACK["on"] and not _PREPACK["busy"]:
+            _PREPACK["list"].setdefault((id(self), which, d.dtype), (weakref.ref(self), weakref.ref(weight), which, d))
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
         w = _master_weight(weight, d)
         check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
+
+
+# Weight packs of a step on a side stream -- opt-in (P2PHD_PREPACK=1), measured SLOWER: 27.33 / 27.39 vs 26.80 / 26.84
+# ms/step at configs[1] B=32 over alternating graph-replayed runs.  The packed images (bf16 forward / input-gradient layouts
+# of every conv) depend only on the master weights, which are final when the step begins, and their ~75 small launches sit
+# in front of each layer's first use; `prepack_weights()` re-packs every image seen in the previous step on a side stream
+# at the start of the step, a layer's first use waits for its own pack only, `join_prepack()` joins the side stream
+# (inside the capture).  Same kernels, same operands, same numbers -- but a second branch in the replayed graph costs the
+# main chain more at its 75 cross-branch edges than the packs cost in line (the same finding as P2PHD_WGRAD_STREAM).
+_PREPACK = {"on": os.environ.get("P2PHD_PREPACK", "0") == "1", "busy": False, "list": {}, "stream": None, "forked": False}
+
+
+def prepack_weights(device):
+    if not _PREPACK["on"] or not _PREPACK["list"] or torch.device(device).type != "cuda":
+        return
+    if _PREPACK["stream"] is None:
+        _PREPACK["stream"] = torch.cuda.Stream(device=device)
+    side, cur = _PREPACK["stream"], torch.cuda.current_stream()
+    side.wait_stream(cur)
+    _PREPACK["busy"] = True
+    try:
+        with torch.cuda.stream(side):
+            for rk, (rs, rw, which, d) in list(_PREPACK["list"].items()):
+                spec, weight = rs(), rw()
+                if spec is None or weight is None:                # the model is gone
+                    del _PREPACK["list"][rk]
+                    continue
+                key = (which, d.dtype)
+                hit = spec._packed.get(key)
+                stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
+                if hit is not None and hit[0] == stamp:
+                    continue
+                spec.packed(weight, which, d)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                spec._pending[key] = ev
+    finally:
+        _PREPACK["busy"] = False
+    _PREPACK["forked"] = True
+
+
+def join_prepack():
+    """Make the current stream wait for every side-stream pack of this step; pending per-layer events are then moot."""
+    if not _PREPACK["forked"]:
+        return
+    torch.cuda.current_stream().wait_stream(_PREPACK["stream"])
+    for rs, _, _, _ in _PREPACK["list"].values():
+        spec = rs()
+        if spec is not None:
+            spec._pending.clear()
+    _PREPACK["forked"] = False
 
 
 def _master_weight(weight, d):

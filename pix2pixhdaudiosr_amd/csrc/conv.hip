@@ -1934,20 +1934,23 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
 }
 
 // bstats[n][c] = sum over tiles (and sub-pixel classes) of the partials one input-gradient launch left (GDesc::bs_out):
-// one wavefront per (sample, channel), lanes over tiles, fixed shuffle tree -> the result does not depend on timing
+// one wavefront per (sample, channel), lanes over tiles, fixed shuffle tree -> the result does not depend on timing.
+// Pad channels [C, Cp) are written as zeros here (they used to cost a memset node per launch).
 __global__ __launch_bounds__(256) void bsum_merge_kernel(const float* __restrict__ part, float* __restrict__ bstats, int tiles,
                                                          int n_extent, int cls_cp, int Cp, int C) {
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * 4 + (threadIdx.x >> 6), n = blockIdx.y;
-  if (c >= C) return;
-  const int ncls = cls_cp > 0 ? 4 : 1;
+  if (c >= Cp) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int t = lane; t < tiles; t += 64)
-    for (int q = 0; q < ncls; ++q) {
-      const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)n * tiles + t) * n_extent + q * cls_cp + c) * 2);
-      s1 += v.x; s2 += v.y;
-    }
-  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (c < C) {
+    const int ncls = cls_cp > 0 ? 4 : 1;
+    for (int t = lane; t < tiles; t += 64)
+      for (int q = 0; q < ncls; ++q) {
+        const float2 v = *reinterpret_cast<const float2*>(part + (((size_t)n * tiles + t) * n_extent + q * cls_cp + c) * 2);
+        s1 += v.x; s2 += v.y;
+      }
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  }
   if (lane == 0) *reinterpret_cast<float2*>(bstats + 2 * ((size_t)n * Cp + c)) = make_float2(s1, s2);
 }
 
@@ -1958,8 +1961,7 @@ namespace p2phd {
 int launch_bsum_merge(const float* table, float* bstats, int N, long npix, int tile_rows, int n_extent, int cls_cp, int Cp, int C,
                       hipStream_t st) {
   const int tiles = (int)((npix + tile_rows - 1) / tile_rows);
-  (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * (size_t)N * Cp, st);       // pad channels read as zero
-  hipLaunchKernelGGL(bsum_merge_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)N), dim3(256), 0, st, table, bstats, tiles, n_extent,
+  hipLaunchKernelGGL(bsum_merge_kernel, dim3((unsigned)((Cp + 3) / 4), (unsigned)N), dim3(256), 0, st, table, bstats, tiles, n_extent,
                      cls_cp, Cp, C);
   return check_launch("bsum_merge");
 }

@@ -312,6 +312,7 @@ class Pix2PixHDModel(BaseModel):
         and the attached pass compute identical values, only their backward differs, so `train_step` walks the one
         retained graph twice (G loss without D weight gradients, then D loss restricted to D's parameters)."""
         _ops.begin_step(self.device)                               # one memset for every statistics / loss accumulator
+        _ops.prepack_weights(self.device)                          # this step's weight images, on a side stream
         lr_spectro, lr_pha, hr_spectro, hr_pha, _, _, hr_norm_param, lr_norm_param = \
             self.encode_input(lr_audio, None, hr_audio, None, noise=noise)
 
@@ -386,6 +387,7 @@ class Pix2PixHDModel(BaseModel):
         # visuals are fetched lazily (no device->host copy in the step)
         self._visual = (lr_spectro, sr_result.detach(), hr_spectro, hr_pha)
         _ops.end_arena(self.device)
+        _ops.join_prepack()
         return self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, loss_G_match, 0, 0, 0, loss_D_real, loss_D_fake), sr_result
 
     def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
