@@ -138,6 +138,9 @@ typedef struct p2phd_conv_desc {
  * parameters to torch as permuted views of the flat buffer (state_dict and checkpoints are unchanged).
  * p2phd_conv_kmajor_ok: 1 if desc (w_layout ignored) may set w_layout = 1. */
 int p2phd_conv_kmajor_ok(const p2phd_conv_desc* c);
+/* 1 if the packed forward image (which = 0) of this bf16 layer with K-major master weights equals bf16(master), element for
+ * element and with no padding rows: see p2phd_adam_step_dev_image */
+int p2phd_conv_fwd_image_is_master(const p2phd_conv_desc* c);
 
 int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
 
@@ -267,6 +270,14 @@ int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * is then constant from step to step and the whole training step can be captured into a HIP graph and replayed. */
 int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
                         int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* The same update, also leaving the new weights as bf16 in `image_bf16` (n elements, same element offsets, 8-byte aligned).
+ * For a conv whose f32 master weights are K-major (p2phd_conv_desc::w_layout = 1) and whose packed forward image is
+ * nothing but their cast (p2phd_conv_fwd_image_is_master), that slice of the image IS the `packed_fwd` argument of
+ * p2phd_conv_fwd: no p2phd_conv_pack_weights call per layer and step (round-2 review item 6a; the reference has no
+ * packed copies at all: optimizer.step() of models/pix2pixHD_model.py:131,140 followed by cuDNN's own layout). */
+int p2phd_adam_step_dev_image(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                              int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* image_bf16,
+                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spectrogram codec (csrc/spectro.hip): Pix2PixHDModel.to_spectro / denormalize / to_audio with

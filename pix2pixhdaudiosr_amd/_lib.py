@@ -37,6 +37,7 @@ SIGNATURES = {
     "p2phd_channel_pitch": (_i32, [_i32]),
     "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2phd_conv_kmajor_ok": (_i32, [_vp]),
+    "p2phd_conv_fwd_image_is_master": (_i32, [_vp]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "p2phd_loss_bwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "p2phd_adam_step_dev_image": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_encode_ex": (_i32, [_vp, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -455,6 +455,13 @@ class ConvSpec:
             if ev is not None:                                    # packed on the side stream of this step (prepack_weights)
                 torch.cuda.current_stream().wait_event(ev)
             return hit[1]
+        # forward image written by FlatAdam's update kernel (optim.py): the layer's slice of the bf16 image IS the packed buffer
+        im = getattr(weight, "_p2phd_image", None) if which == 0 else None
+        if im is not None and im["stamp"] == stamp[:2] and d.w_layout == 1 and lib().p2phd_conv_fwd_image_is_master(C.byref(d)):
+            nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), 0)
+            buf = im["buf"][:nbytes // 2].view(torch.uint8)
+            self._packed[key] = (stamp, buf)
+            return buf
         if _PREPACK["on"] and not _PREPACK["busy"]:
             _PREPACK["list"].setdefault((id(self), which, d.dtype), (weakref.ref(self), weakref.ref(weight), which, d))
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)

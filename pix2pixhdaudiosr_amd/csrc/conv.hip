@@ -2095,6 +2095,12 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
   return check_launch("pack_weights(merged)");
 }
 
+// true when launch_pack would be nothing but a cast of the K-major master rows (no K tail, no padding rows): the bf16 image
+// FlatAdam's update kernel writes beside the f32 master weights IS the packed forward image (p2phd_conv_fwd_image_is_master)
+bool pack_is_master_cast(const GDesc& d, const WMap& m, int rows_pad) {
+  return d.cls_cp == 0 && kmajor_dense_map(d, m) && d.KK % 4 == 0 && d.KK == d.nth * d.ntw * m.inner && rows_pad == m.rows;
+}
+
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
   if (rows_pad <= 0) return P2PHD_OK;
   if (kmajor_dense_map(d, m) && d.KK % 4 == 0) {

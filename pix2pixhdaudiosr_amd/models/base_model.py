@@ -54,3 +54,6 @@ class BaseModel(torch.nn.Module):
                 print(missing)
                 network.load_state_dict(merged)
         _ops.bump_weight_epoch()
+        # captured steps read the bf16 forward images the optimiser's update kernel keeps (optim.FlatAdam): weights that
+        # changed any other way need a fresh capture (and one eager update to refresh the images)
+        self._graph_state = None

@@ -715,3 +715,47 @@ def test_kmajor_master_weights(dtype, tol, geom):
         go = torch.autograd.grad((yo * cot.cpu()).sum(), [xo, wo])
         assert rel_err(res[1][0].numpy(), yo.detach().numpy()) < 1e-4
         assert rel_err(res[1][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(res[1][2].numpy(), go[1].numpy()) < 3e-4
+
+
+def test_forward_image_written_by_the_update_kernel(monkeypatch):
+    """Opt-in P2PHD_ADAM_IMAGE=1 (round-2 review item 6a): FlatAdam's update kernel also writes the new weights as bf16 at
+    the same element offsets; for a K-major layer whose packed forward image is a plain cast that slice replaces the pack
+    launch.  Same bits as the pack kernel, taken only while nothing else wrote the parameter."""
+    import ctypes as C
+    from pix2pixhdaudiosr_amd import _ops
+    from pix2pixhdaudiosr_amd.optim import FlatAdam
+    monkeypatch.setenv("P2PHD_ADAM_IMAGE", "1")
+    cin, cout, k, N, H, W = 64, 128, 3, 2, 12, 10
+    g = torch.Generator().manual_seed(29)
+    w = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda())
+    b = torch.nn.Parameter(torch.zeros(5).cuda())                      # a second parameter in front: a non-zero, 16-byte aligned offset
+    w._p2phd_kmajor = True
+    opt = FlatAdam([b, w], lr=1e-2)
+    assert opt._image is not None and opt.param_offset(1) % 8 == 0
+    spec = _ops.ConvSpec(cin, cout, k, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, torch.bfloat16, 1)
+    assert _ops.lib().p2phd_conv_fwd_image_is_master(C.byref(d)) == 1
+    lo, hi = opt._image.data_ptr(), opt._image.data_ptr() + opt._image.numel() * 2
+    x = torch.randn(N, cin, H, W, generator=g).cuda()
+
+    def fwd():
+        return _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, x), w, None, spec), cout).detach().clone()
+
+    fwd()
+    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)          # no update yet: the pack kernel's own buffer
+    opt.zero_grad()
+    w.grad.normal_(generator=None)
+    opt.step()
+    y_img = fwd()
+    assert lo <= spec.packed(w, 0, d).data_ptr() < hi                 # the optimiser's image, no pack launch
+    w._p2phd_image["stamp"] = None                                    # same weights through the pack kernel
+    _ops.bump_weight_epoch()
+    y_pack = fwd()
+    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)
+    assert torch.equal(y_img, y_pack)
+    opt.step()                                                        # image valid again ...
+    with torch.no_grad():
+        w.mul_(1.5)                                                   # ... until torch writes the parameter
+    y_new = fwd()
+    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)
+    assert not torch.equal(y_new, y_pack) and torch.isfinite(y_new).all()
