@@ -478,7 +478,8 @@ class ConvSpec:
 # in front of each layer's first use; `prepack_weights()` re-packs every image seen in the previous step on a side stream
 # at the start of the step, a layer's first use waits for its own pack only, `join_prepack()` joins the side stream
 # (inside the capture).  Same kernels, same operands, same numbers -- but a second branch in the replayed graph costs the
-# main chain more at its 75 cross-branch edges than the packs cost in line (the same finding as P2PHD_WGRAD_STREAM).
+# main chain more at its 75 cross-branch edges than the packs cost in line (the same finding as P2PHD_WGRAD_STREAM), and
+# a pack right in front of its conv is also what leaves the weights in the Infinity Cache for it (optim.FlatAdam._image).
 _PREPACK = {"on": os.environ.get("P2PHD_PREPACK", "0") == "1", "busy": False, "list": {}, "stream": None, "forked": False}
 
 
