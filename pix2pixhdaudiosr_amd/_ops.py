@@ -460,12 +460,14 @@ class ConvSpec:
         if im is not None and im["stamp"] == stamp[:2] and d.w_layout == 1 and lib().p2phd_conv_fwd_image_is_master(C.byref(d)):
             nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), 0)
             buf = im["buf"][:nbytes // 2].view(torch.uint8)
+            buf._p2phd_is_image = True                            # never handed to the pack kernel as its output
             self._packed[key] = (stamp, buf)
             return buf
         if _PREPACK["on"] and not _PREPACK["busy"]:
             _PREPACK["list"].setdefault((id(self), which, d.dtype), (weakref.ref(self), weakref.ref(weight), which, d))
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
-        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
+        reuse = hit is not None and hit[1].numel() == nbytes and not getattr(hit[1], "_p2phd_is_image", False)
+        buf = hit[1] if reuse else empty((nbytes,), torch.uint8, weight.device)
         w = _master_weight(weight, d)
         check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
         self._packed[key] = (stamp, buf)
