@@ -1740,11 +1740,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, lo
 #pragma unroll
   for (int k = 0; k < EPP; ++k) acc[k] = 0.f;
   if (pc < cpr) {
-    for (long p = (long)blockIdx.x * R + rl; p < P; p += (long)gridDim.x * R) {
-      const uint4 v = *reinterpret_cast<const uint4*>(x + (size_t)p * Cp + pc * EPP);
-      const T* vv = reinterpret_cast<const T*>(&v);
+    // four rows per trip, all requested before the first is added (one 16-byte load in flight per thread left this pass at
+    // 2.7 TB/s); rows past the end re-read the last one and are masked in the sum (no branch around a load)
+    constexpr int U = 4;
+    const long stride = (long)gridDim.x * R;
+    for (long p0 = (long)blockIdx.x * R + rl; p0 < P; p0 += stride * U) {
+      uint4 v[U];
 #pragma unroll
-      for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]);
+      for (int u = 0; u < U; ++u) {
+        const long p = p0 + stride * u;
+        v[u] = *reinterpret_cast<const uint4*>(x + (size_t)(p < P ? p : P - 1) * Cp + pc * EPP);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float live = p0 + stride * u < P ? 1.f : 0.f;
+        const T* vv = reinterpret_cast<const T*>(&v[u]);
+#pragma unroll
+        for (int k = 0; k < EPP; ++k) acc[k] += to_f(vv[k]) * live;
+      }
     }
   }
 #pragma unroll
