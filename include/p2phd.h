@@ -189,6 +189,9 @@ int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const void* packe
  * Available when p2phd_conv_dgrad_bsum_ok(desc) (one direct gather-GEMM launch: no reflect padding, no W-fold, not the
  * dedicated 7x7 kernel); workspace: p2phd_conv_dgrad_bsum_workspace_bytes (this call does not need the plain dgrad workspace). */
 int p2phd_conv_dgrad_bsum_ok(const p2phd_conv_desc* c);
+/* advisory: 0 where the fused form is available but slower than p2phd_conv_dgrad + the two-pass backward (the plain input
+ * gradient would run on the 256 x 256 tile, which has no fused store loop: the discriminator's 256 -> 512 layer) */
+int p2phd_conv_dgrad_bsum_pays(const p2phd_conv_desc* c);
 size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c);
 int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, const void* packed, const void* addend, void* dx,
                           const void* prev_y, const float* prev_stats, int prev_act, float eps, float* bstats,

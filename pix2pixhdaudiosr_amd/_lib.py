@@ -49,6 +49,7 @@ SIGNATURES = {
     "p2phd_conv_dgrad_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_dgrad": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_conv_dgrad_bsum_ok": (_i32, [_vp]),
+    "p2phd_conv_dgrad_bsum_pays": (_i32, [_vp]),
     "p2phd_conv_dgrad_bsum_workspace_bytes": (_sz, [_vp]),
     "p2phd_conv_dgrad_bsum": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_conv_dgrad_act": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

@@ -272,6 +272,7 @@ def workspace(nbytes, device, tag=""):
 # MFMA rounds (231 / 243 workgroups on 256 CUs) and the HBM-bound normalisation / slab-sum kernels fill each other's gaps.
 # Operands of a side-stream launch are kept alive until the join (the caching allocator orders reuse per stream only);
 # under graph capture the wait/join pairs become graph edges.
+_BSUM_ALWAYS = os.environ.get("P2PHD_BSUM_ALWAYS", "0") == "1"     # A/B: fuse wherever possible, also where it measured slower
 _SIDE = {"on": False, "stream": None, "keep": [], "used": False}
 
 
@@ -741,7 +742,7 @@ class ConvBlockFn(torch.autograd.Function):
             fuse = (src is not None and src.spec.norm and src._p2phd_consumers == 1 and _bsum_enabled() and src_y is not None
                     and src_y.shape == x.shape and src_y.dtype == x.dtype and src.spec.act in (ACT_NONE, ACT_RELU, ACT_LRELU)
                     and L.p2phd_instnorm_act_bwd_two_pass(d.dtype, x.shape[0], x.shape[1] * x.shape[2], spec.cin)
-                    and L.p2phd_conv_dgrad_bsum_ok(C.byref(d)))
+                    and (L.p2phd_conv_dgrad_bsum_ok(C.byref(d)) if _BSUM_ALWAYS else L.p2phd_conv_dgrad_bsum_pays(C.byref(d))))
             if fuse:
                 _check_arena(src, y.device)
                 bst = empty((x.shape[0], x.shape[3], 2), torch.float32, y.device)

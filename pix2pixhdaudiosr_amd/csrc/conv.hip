@@ -1946,6 +1946,39 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   return launch_gconv_cfg<T, 128, 32, 1, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
 }
 
+}  // namespace
+
+namespace p2phd {
+
+// launch_gconv_t's tile choice for a bf16 launch WITHOUT statistics / fused sums: does it take the 256 x 256 tile?  That
+// tile has no fused store loop, so an input gradient carrying the producer's InstanceNorm-backward sums falls back to
+// 256 x 128 tiles and loses more (D 128->256 <- 256->512 at B = 64: 735 + 40 us against 539 + 89 us for plain input
+// gradient + two-pass backward) than the saved pass is worth: p2phd_conv_dgrad_bsum_pays says no for such a layer.
+bool gconv_plain_launch_takes_256x256(const GDesc& d_in, int dtype) {
+  if (dtype != P2PHD_BF16) return false;
+  const int k = d_in.n_extent ? d_in.n_extent : d_in.Cp_out;
+  const int npix = d_in.Hg * d_in.Wg, taps = d_in.nth * d_in.ntw;
+  const bool flat = npix % 256 != 0;
+  const long mt256 = flat ? ((long)d_in.N * npix + 255) / 256 : (long)((npix + 255) / 256) * d_in.N;
+  const long tabb = (long)taps * 256 * 4 + 16 + 256 * 8, kLds = 160 * 1024;
+  const bool enough_px = flat ? (long)d_in.N * npix >= 2048 : (npix >= 256 && (npix % 256 == 0 || npix >= 2048));
+  const bool fits_huge = 2 * 512 * kRowBytes + tabb <= kLds && 256 * (256 * 2 + 16) + tabb <= kLds;
+  bool huge = fits_huge && enough_px && k >= 256 && (k % 256 == 0 || k >= 1024) && mt256 * ((k + 255) / 256) >= 160;
+  const int force = g_opt_gconv_bm;
+  if (force == 512) huge = fits_huge && k > 128;
+  else if (force != 0) huge = false;
+  if (huge && force == 0 && k % 192 == 0) {
+    const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
+    const double c256 = std::ceil(wg256 / 256.0) * 256.0 * 256.0, c192 = std::ceil(wg192 / 256.0) * 256.0 * 192.0 / 0.95;
+    if (c192 < c256 && 2 * 448 * kRowBytes + tabb <= kLds) huge = false;
+  }
+  return huge;
+}
+
+}  // namespace p2phd
+
+namespace {
+
 // bstats[n][c] = sum over tiles (and sub-pixel classes) of the partials one input-gradient launch left (GDesc::bs_out):
 // one wavefront per (sample, channel), lanes over tiles, fixed shuffle tree -> the result does not depend on timing.
 // Pad channels [C, Cp) are written as zeros here (they used to cost a memset node per launch).

@@ -560,6 +560,13 @@ extern "C" int p2phd_conv_dgrad_bsum_ok(const p2phd_conv_desc* c) {
   return dgrad_bsum_plans(c, plans) ? 1 : 0;
 }
 
+extern "C" int p2phd_conv_dgrad_bsum_pays(const p2phd_conv_desc* c) {
+  std::vector<Plan> plans;
+  if (!dgrad_bsum_plans(c, plans)) return 0;
+  // (deep reductions only: on the generator's 3072..3456-deep layers the two extra reduce launches cost what the tile gains)
+  return (gconv_plain_launch_takes_256x256(plans[0].d, c->dtype) && plans[0].d.KK >= 6144) ? 0 : 1;
+}
+
 extern "C" size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c) {
   std::vector<Plan> plans;
   if (!dgrad_bsum_plans(c, plans)) return 0;

@@ -119,6 +119,7 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
                        long s_k, long s_c, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
 bool pack_is_master_cast(const GDesc& d, const WMap& m, int rows_pad);
+bool gconv_plain_launch_takes_256x256(const GDesc& d, int dtype);
 int launch_reflect_expand(int dtype, const void* dy, void* e_out, int N, int H, int W, int Cp, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,
                         hipStream_t st);

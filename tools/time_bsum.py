@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from pix2pixhdaudiosr_amd import _ops
 L = _ops.lib()
-B, dt = 32, torch.bfloat16
+B, dt = int(os.environ.get("B", "32")), torch.bfloat16
 
 def t_us(fn, it=5):
     fn(); torch.cuda.synchronize()
