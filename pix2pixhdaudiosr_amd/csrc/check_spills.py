@@ -7,7 +7,7 @@ text = open(sys.argv[1]).read()
 bad, seen = [], 0
 for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", text, re.S):
     name, scratch = m.group(1), int(m.group(2))
-    if "gconv_kernel" in name or "wgrad_kernel" in name:
+    if "gconv_kernel" in name or "gconv_pkernel" in name or "wgrad_kernel" in name:
         seen += 1
         if scratch:
             bad.append((name, scratch))

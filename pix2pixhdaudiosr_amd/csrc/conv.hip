@@ -831,6 +831,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
 }
 
+#include "gconv_persist.inc"
+
 // ------------------------------------------------------------------------------------------------------
 // weight gradient:  dWp[split][m][t*Cg + c] = sum_{p in split} rows[p][m] * gather[pix(p,t)][c]
 //   rows   : [N*Hg*Wg][Cp_r]   the tensor on the pixel grid (dy for Conv2d, x for ConvTranspose2d)
@@ -1828,12 +1830,27 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   d.grid_m = mtiles;
   d.sk_first = TT; d.sk_tail = 1; d.sk_parts = 1; d.sk_steps = 0; d.sk_part = nullptr; d.sk_ticket = nullptr;
   int wgs = TT;
-  if (p2phd::g_opt_splitk_tail != 0) {
-    static int cus = 0;
-    if (cus == 0) {
-      int dev = 0; hipDeviceProp_t prop;
-      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0; hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  // Persistent form (gconv_persist.inc): one workgroup per CU walks its tiles and fills the next tile's ring under the
+  // current epilogue.  Forward-type launches of many tiles on the two tile shapes that carry the short-K / medium-K layers.
+  constexpr bool kPersistCfg = sizeof(T) == 2 && BM == 256 && MR * NR <= 6 && BN == 128 && NSTAGE == 3;
+  if constexpr (kPersistCfg) {
+    const size_t lds_p = (size_t)tab + BM * 8 + (size_t)NSTAGE * STAGE;
+    if (p2phd::g_opt_gconv_persist != 0 && d.act != P2PHD_ACT_TANH && d.bs_out == nullptr && d.as_x == nullptr && addend == nullptr && TT >= 2 * cus &&
+        d.KK / (8 * Elem<T>::EPP) >= NSTAGE && lds_p <= 160 * 1024) {
+      auto pk = gconv_pkernel<T, BM, BN, MR, NR, NSTAGE>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
+      typedef typename OutOf<T>::type TOp;
+      hipLaunchKernelGGL(pk, dim3((unsigned)cus), dim3((BM / (MR * 32)) * (BN / (NR * 32)) * 64), lds_p, st, d, (const T*)in, (const T*)wp, bias,
+                         (TOp*)out, stats);
+      return p2phd::check_launch("gconv(persistent)");
     }
+  }
+  if (p2phd::g_opt_splitk_tail != 0) {
     const int nsteps = d.KK / (8 * Elem<T>::EPP);
     const int full = TT / cus * cus, tail = TT - full;
     // Cost model in microseconds (layer tables of profiles/r03_*): a K slab of a BM x BN tile at the rate one CU sustains in

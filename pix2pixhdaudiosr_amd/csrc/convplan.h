@@ -67,6 +67,8 @@ extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
 extern int g_opt_c7_generic;
 extern int g_opt_splitk_tail;       // 0: every tile is one workgroup, 1 (default): split-K tail where the cost model says so, 2: wherever possible (tests)
+extern int g_opt_gconv_persist;     // 1: forward-type launches of >= 2 tiles per CU on 256 x 128 tiles take the persistent kernel (gconv_persist.inc);
+                                    // default 0: bit-exact but at break-even so far
 extern int g_opt_reflect_generic;   // 1: reflect-padded 3x3 input gradients on the padded grid + fold (the general form)
 extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 

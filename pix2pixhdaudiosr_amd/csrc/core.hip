@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace p2phd
 
-namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; }
+namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_gconv_persist = 0; }
 
 // scratch of the fixed-order cross-workgroup reductions (common.h): zero-initialised with the code object
 namespace {
@@ -48,6 +48,7 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "reflect_generic") && (value == 0 || value == 1)) { p2phd::g_opt_reflect_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_iters") && value >= 0 && value <= 8) { p2phd::g_opt_mdct_iters = value; return P2PHD_OK; }
   if (name && !strcmp(name, "splitk_tail") && value >= 0 && value <= 2) { p2phd::g_opt_splitk_tail = value; return P2PHD_OK; }
+  if (name && !strcmp(name, "gconv_persist") && (value == 0 || value == 1)) { p2phd::g_opt_gconv_persist = value; return P2PHD_OK; }
   if (name && !strcmp(name, "c7_abl")) { p2phd::g_opt_c7_abl = value; return P2PHD_OK; }
   if (name && !strcmp(name, "c7_generic") && (value == 0 || value == 1)) { p2phd::g_opt_c7_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_generic") && (value == 0 || value == 1)) { p2phd::g_opt_mdct_generic = value; return P2PHD_OK; }
