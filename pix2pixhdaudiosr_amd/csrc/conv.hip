@@ -1837,7 +1837,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   }
   // Persistent form (gconv_persist.inc): one workgroup per CU walks its tiles and fills the next tile's ring under the
   // current epilogue.  Forward-type launches of many tiles on the two tile shapes that carry the short-K / medium-K layers.
-  constexpr bool kPersistCfg = sizeof(T) == 2 && BM == 256 && MR * NR <= 6 && BN == 128 && NSTAGE == 3;
+  constexpr bool kPersistCfg = sizeof(T) == 2 && BM == 256 && MR * NR <= 6 && BN == 128 && NSTAGE == 3;   // (256 x 192 on its 2-slot ring: built, bit-exact, 4-7 % SLOWER -- one prefetched stage is not enough)
   if constexpr (kPersistCfg) {
     const size_t lds_p = (size_t)tab + BM * 8 + (size_t)NSTAGE * STAGE;
     if (p2phd::g_opt_gconv_persist != 0 && d.act != P2PHD_ACT_TANH && d.bs_out == nullptr && d.as_x == nullptr && addend == nullptr && TT >= 2 * cus &&
