@@ -148,10 +148,16 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)b2, t));
   for (long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long)gridDim.x * 256 * 4) {
     if (e + 4 <= n) {
+      // the two moment buffers (and the gradient) are touched by nothing else in a step: streamed past the caches
+      // (non-temporal), so that the weights stay resident for the next step's packs
+      typedef __attribute__((ext_vector_type(4))) float f4v;
       float4 pp = *reinterpret_cast<float4*>(p + e);
-      const float4 gg = *reinterpret_cast<const float4*>(g + e);
-      float4 mm = *reinterpret_cast<float4*>(m + e);
-      float4 vv = *reinterpret_cast<float4*>(v + e);
+      const f4v gq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g + e));
+      const f4v mq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(m + e));
+      const f4v vq = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(v + e));
+      const float4 gg = make_float4(gq.x, gq.y, gq.z, gq.w);
+      float4 mm = make_float4(mq.x, mq.y, mq.z, mq.w);
+      float4 vv = make_float4(vq.x, vq.y, vq.z, vq.w);
       float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -161,8 +167,11 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
         pa[k] -= (lr / bc1) * ma[k] / (sqrtf(va[k]) / bc2_sqrt + eps);
       }
       *reinterpret_cast<float4*>(p + e) = pp;
-      *reinterpret_cast<float4*>(m + e) = mm;
-      *reinterpret_cast<float4*>(v + e) = vv;
+      {
+        const f4v mo = {mm.x, mm.y, mm.z, mm.w}, vo = {vv.x, vv.y, vv.z, vv.w};
+        __builtin_nontemporal_store(mo, reinterpret_cast<f4v*>(m + e));
+        __builtin_nontemporal_store(vo, reinterpret_cast<f4v*>(v + e));
+      }
       if constexpr (SHADOW) {
         typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
         const bf16x4_ sb = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3]};
