@@ -414,7 +414,7 @@ def main():
         if a.fp8:
             from pix2pixhdaudiosr_amd import _ops as _o
             out["fp8"] = {"layers_switched": model.fp8_layers, "fp8_conv_launches_recorded_by_the_host": _o._FP8_CALLS[0],
-                          "what": "OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 for the forward of the stride-1 convs with >= 256 "
+                          "what": "OCP e4m3 operands on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit e8m0 scales, 2x the bf16 rate) for the forward of the stride-1 convs with >= 256 "
                                   "input channels; fp32 master weights, bf16 activations and the bf16 backward unchanged"}
         if dist_info is not None:
             out["dist"] = dist_info

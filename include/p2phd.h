@@ -15,6 +15,15 @@
  *   - return 0 on success, a negative P2PHD_E* code otherwise; p2phd_last_error() gives text
  *     (thread-local);
  *   - thread-compatible, not thread-safe per output buffer.
+ *
+ * Streams
+ *   The kernels that reduce across workgroups without float atomics (InstanceNorm backward sums, bias column sums, loss
+ *   accumulators, the split-K tail of the conv GEMM) keep their partial rows and arrival tickets in a scratch that belongs
+ *   to the library, one region per kernel family.  A region serves ONE stream at a time: entry points remember the last
+ *   stream that used each region, and a call that arrives on another stream while that stream still has work in flight
+ *   returns P2PHD_EINVAL (p2phd_last_error names the region) instead of mixing partials.  Order the streams first (event
+ *   wait, synchronisation, graph capture boundary), or keep one compute stream per process.  p2phd_reduction_reset(stream)
+ *   re-arms the tickets; call it once per training step (a faulted or aborted launch could otherwise leave one armed wrong).
  */
 #ifndef P2PHD_H
 #define P2PHD_H
@@ -41,6 +50,8 @@ int p2phd_abi_version(void);
 int p2phd_device_info(char* name, int cap);
 /* tuning overrides for tests and A/B timing: "gconv_bm" = 0 (heuristic) | 128 | 256 */
 int p2phd_set_option(const char* name, int value);
+/* zeroes the arrival tickets of the fixed-order reductions on `stream` (13 KB memset; see "Streams" above) */
+int p2phd_reduction_reset(void* stream);
 /* Measurement hook (bench.py's roofline): while armed, every launch of the implicit-GEMM conv kernel whose gathered
  * tensor has `cin_pitch` channels, whose GEMM-K is `kk` and whose pixel grid is hg x wg is bracketed by HIP events on its
  * own launch stream (the kernel alone: none of the companion launches of p2phd_conv_fwd).  p2phd_probe_read waits for
@@ -138,10 +149,6 @@ typedef struct p2phd_conv_desc {
  * parameters to torch as permuted views of the flat buffer (state_dict and checkpoints are unchanged).
  * p2phd_conv_kmajor_ok: 1 if desc (w_layout ignored) may set w_layout = 1. */
 int p2phd_conv_kmajor_ok(const p2phd_conv_desc* c);
-/* 1 if the packed forward image (which = 0) of this bf16 layer with K-major master weights equals bf16(master), element for
- * element and with no padding rows: see p2phd_adam_step_dev_image */
-int p2phd_conv_fwd_image_is_master(const p2phd_conv_desc* c);
-
 int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
 
 /* Packed (K-contiguous, tap-major, zero-padded) weights for the forward (which = 0) or the input-gradient
@@ -252,6 +259,11 @@ int p2phd_avgpool3s2_bwd(int dtype, const void* dy, void* dx, int N, int H, int 
 /* Module-boundary layout converters: f32 NCHW [N,C,HW] <-> channels [ch_off, ch_off+C) of NHWC [N,HW,Cp]. */
 int p2phd_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream);
 int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream);
+/* torch.cat((x0, x1, ...), dim=1) of up to four f32 NCHW tensors (pix2pixHD_model.py:56,307,360: the discriminator's
+ * input) straight into NHWC [N,HW,Cp]: `srcs` / `chans` are HOST arrays of nsrc device pointers / channel counts; every
+ * 16-byte piece of dst is written once, pad channels as zeros (no memset of dst, one launch). */
+int p2phd_nchw_cat_to_nhwc(int dtype, const float* const* srcs, const int* chans, int nsrc, void* dst, int N, int64_t HW, int Cp,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Losses and optimiser (csrc/loss.hip).
@@ -273,14 +285,6 @@ int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * is then constant from step to step and the whole training step can be captured into a HIP graph and replayed. */
 int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
                         int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
-/* The same update, also leaving the new weights as bf16 in `image_bf16` (n elements, same element offsets, 8-byte aligned).
- * For a conv whose f32 master weights are K-major (p2phd_conv_desc::w_layout = 1) and whose packed forward image is
- * nothing but their cast (p2phd_conv_fwd_image_is_master), that slice of the image IS the `packed_fwd` argument of
- * p2phd_conv_fwd: no p2phd_conv_pack_weights call per layer and step (round-2 review item 6a; the reference has no
- * packed copies at all: optimizer.step() of models/pix2pixHD_model.py:131,140 followed by cuDNN's own layout). */
-int p2phd_adam_step_dev_image(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
-                              int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* image_bf16,
-                              void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Spectrogram codec (csrc/spectro.hip): Pix2PixHDModel.to_spectro / denormalize / to_audio with

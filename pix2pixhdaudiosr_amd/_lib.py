@@ -22,6 +22,7 @@ SIGNATURES = {
     "p2phd_abi_version": (_i32, []),
     "p2phd_device_info": (_i32, [C.c_char_p, _i32]),
     "p2phd_set_option": (_i32, [C.c_char_p, _i32]),
+    "p2phd_reduction_reset": (_i32, [_vp]),
     "p2phd_probe_gconv": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_gconv_ex": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_read": (_i32, [_vp, _i32]),
@@ -37,7 +38,6 @@ SIGNATURES = {
     "p2phd_channel_pitch": (_i32, [_i32]),
     "p2phd_conv_out_size": (_i32, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "p2phd_conv_kmajor_ok": (_i32, [_vp]),
-    "p2phd_conv_fwd_image_is_master": (_i32, [_vp]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
     "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
@@ -67,12 +67,12 @@ SIGNATURES = {
     "p2phd_avgpool3s2_fwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2phd_avgpool3s2_bwd": (_i32, [_i32, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "p2phd_nchw_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+    "p2phd_nchw_cat_to_nhwc": (_i32, [_i32, _vp, _vp, _i32, _vp, _i32, _i64, _i32, _vp]),
     "p2phd_nhwc_to_nchw": (_i32, [_i32, _vp, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
     "p2phd_loss_fwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp]),
     "p2phd_loss_bwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
-    "p2phd_adam_step_dev_image": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_encode_ex": (_i32, [_vp, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -7,7 +7,6 @@ C ABI, and ``torch.autograd.Function`` wrappers whose backward calls the HIP bac
 """
 import ctypes as C
 import contextlib
-import weakref
 
 import os
 import torch
@@ -51,6 +50,7 @@ def begin_step(device, nbytes=32 << 20):
         a = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=device), "off": 0, "live": False}
         _ARENA[device] = a
     a["buf"].zero_()
+    check(lib().p2phd_reduction_reset(stream_ptr()), "reduction_reset")      # tickets of the fixed-order reductions: re-armed per step
     a["off"], a["live"] = 0, True
     a["gen"] = a.get("gen", 0) + 1
 
@@ -150,10 +150,23 @@ def backward_on_samples(n_full, lo, hi):
         _BWD_RANGE.update(prev)
 
 
-def _bwd_range(n):
-    if _BWD_RANGE["n_full"] is not None and _BWD_RANGE["n_full"] == int(n):
+def _bwd_range(n, paired=True):
+    """The sample range a backward Function of batch size n is restricted to, or None.  `paired`: the Function was tagged
+    in its forward as part of the stacked (real | fake) discriminator pass (its input descends from ToPhysicalPair); an
+    untagged Function that merely has the same batch size is never truncated."""
+    if paired and _BWD_RANGE["n_full"] is not None and _BWD_RANGE["n_full"] == int(n):
         return _BWD_RANGE["lo"], _BWD_RANGE["hi"]
     return None
+
+
+def _is_pair(t):
+    return bool(getattr(t, "_p2phd_pair", False))
+
+
+def _tag_pair(out, src):
+    if _is_pair(src):
+        out._p2phd_pair = True
+    return out
 
 
 def _direct_grad(p):
@@ -263,44 +276,7 @@ def workspace(nbytes, device, tag=""):
     return t
 
 
-# ------------------------------------------------------------------------------------------
-# weight gradients on a second stream
-# ------------------------------------------------------------------------------------------
-# Inside `wgrad_side_stream()` (the model's backward stages) ConvBlockFn.backward launches its weight-gradient kernels on a
-# side stream: they depend only on (x, dy) and write the flat gradient buffer nobody reads before the stage ends, so
-# they run beside the input-gradient chain (dgrad -> InstanceNorm backward of the previous layer -> ...): under-filled
-# MFMA rounds (231 / 243 workgroups on 256 CUs) and the HBM-bound normalisation / slab-sum kernels fill each other's gaps.
-# Operands of a side-stream launch are kept alive until the join (the caching allocator orders reuse per stream only);
-# under graph capture the wait/join pairs become graph edges.
 _BSUM_ALWAYS = os.environ.get("P2PHD_BSUM_ALWAYS", "0") == "1"     # A/B: fuse wherever possible, also where it measured slower
-_SIDE = {"on": False, "stream": None, "keep": [], "used": False}
-
-
-def _side_stream(device):
-    if _SIDE["stream"] is None:
-        _SIDE["stream"] = torch.cuda.Stream(device=device)
-    return _SIDE["stream"]
-
-
-class wgrad_side_stream:
-    """Context manager: weight gradients of every ConvBlockFn.backward inside run on the side stream; leaving it makes the
-    current stream wait for them.  Opt-in (P2PHD_WGRAD_STREAM=1): measured 29.72 vs 29.84 ms/step at configs[1] B=32 with
-    graph replay, i.e. inside run-to-run noise -- two MFMA kernels that each want every CU's LDS do not co-run, and the
-    HBM-bound companions are too short to matter -- so the default keeps the single-stream order."""
-
-    def __enter__(self):
-        self.prev = _SIDE["on"]
-        _SIDE["on"] = os.environ.get("P2PHD_WGRAD_STREAM", "0") == "1"
-        _SIDE["used"] = False
-        return self
-
-    def __exit__(self, *exc):
-        if _SIDE["used"]:
-            torch.cuda.current_stream().wait_stream(_SIDE["stream"])
-        _SIDE["keep"].clear()
-        _SIDE["used"] = False
-        _SIDE["on"] = self.prev
-        return False
 
 
 def phys(t, what="activation"):
@@ -316,15 +292,24 @@ def phys(t, what="activation"):
 # layout
 # ------------------------------------------------------------------------------------------
 
-def to_physical(x_nchw, dtype, out=None, ch_off=0):
-    """f32 NCHW -> NHWC physical (channels [ch_off, ch_off+C)); `out` lets several tensors be concatenated."""
-    x = x_nchw.contiguous().float()
-    N, Cc, H, W = x.shape
+def cat_to_physical(xs, dtype, out=None):
+    """torch.cat(xs, dim=1) of f32 NCHW tensors -> NHWC physical, pad channels written as zeros by the same launch
+    (`out`: a [N,H,W,Cp] tensor -- or batch slice of one -- to fill)."""
+    xs = [x.contiguous().float() for x in xs]
+    N, _, H, W = xs[0].shape
+    chans = [int(x.shape[1]) for x in xs]
     if out is None:
-        out = empty((N, H, W, cpitch(ch_off + Cc)), dtype, x.device).zero_()
-    check(lib().p2phd_nchw_to_nhwc(dt_code(out.dtype), ptr(x), ptr(out), N, Cc, H * W, out.shape[-1], ch_off, stream_ptr()),
-          "nchw_to_nhwc")
+        out = empty((N, H, W, cpitch(sum(chans))), dtype, xs[0].device)
+    srcs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
+    cc = (C.c_int32 * len(xs))(*chans)
+    check(lib().p2phd_nchw_cat_to_nhwc(dt_code(out.dtype), srcs, cc, len(xs), ptr(out), N, H * W, out.shape[-1], stream_ptr()),
+          "nchw_cat_to_nhwc")
     return out
+
+
+def to_physical(x_nchw, dtype):
+    """f32 NCHW -> NHWC physical."""
+    return cat_to_physical([x_nchw], dtype)
 
 
 def from_physical(x_phys, channels, ch_off=0):
@@ -336,19 +321,12 @@ def from_physical(x_phys, channels, ch_off=0):
 
 
 class ToPhysical(torch.autograd.Function):
-    """NCHW f32 (one or two tensors concatenated along channels) -> physical NHWC."""
+    """NCHW f32 (one or several tensors concatenated along channels) -> physical NHWC."""
 
     @staticmethod
     def forward(ctx, dtype, *xs):
         ctx.chans = [int(x.shape[1]) for x in xs]
-        total = sum(ctx.chans)
-        N, _, H, W = xs[0].shape
-        out = empty((N, H, W, cpitch(total)), dtype, xs[0].device).zero_()
-        off = 0
-        for x in xs:
-            to_physical(x, dtype, out=out, ch_off=off)
-            off += int(x.shape[1])
-        return out
+        return cat_to_physical(xs, dtype)
 
     @staticmethod
     def backward(ctx, g):
@@ -368,10 +346,9 @@ class ToPhysicalPair(torch.autograd.Function):
     def forward(ctx, dtype, a, b_real, b_fake):
         B, ca, H, W = a.shape
         cb = int(b_real.shape[1])
-        out = empty((2 * B, H, W, cpitch(ca + cb)), dtype, a.device).zero_()
-        for half, other in ((out[:B], b_real), (out[B:], b_fake)):
-            to_physical(a, dtype, out=half, ch_off=0)
-            to_physical(other, dtype, out=half, ch_off=ca)
+        out = empty((2 * B, H, W, cpitch(ca + cb)), dtype, a.device)
+        cat_to_physical((a, b_real), dtype, out=out[:B])
+        cat_to_physical((a, b_fake), dtype, out=out[B:])
         ctx.meta = (B, ca, cb)
         return out
 
@@ -379,7 +356,20 @@ class ToPhysicalPair(torch.autograd.Function):
     def backward(ctx, g):
         B, ca, cb = ctx.meta
         g = g.contiguous()
+        if ctx.needs_input_grad[3] and _bwd_range(2 * B) != (B, 2 * B):
+            # the Functions below wrote the fake half only if they ran inside backward_on_samples(2B, B, 2B); outside it
+            # they wrote everything, which is fine too -- but a DIFFERENT range would have left the fake half unwritten
+            if _BWD_RANGE["n_full"] == 2 * B:
+                raise _lib.P2PHDError("ToPhysicalPair.backward: the sample-range backward does not cover the fake half")
         return None, None, None, (from_physical(g[B:], cb, ca) if ctx.needs_input_grad[3] else None)
+
+
+def to_physical_pair(dtype, a, b_real, b_fake):
+    """ToPhysicalPair, with the result tagged so that the Functions consuming it (and their outputs, transitively) take part
+    in a sample-range backward (backward_on_samples)."""
+    out = ToPhysicalPair.apply(dtype, a, b_real, b_fake)
+    out._p2phd_pair = True
+    return out
 
 
 class FromPhysical(torch.autograd.Function):
@@ -393,9 +383,7 @@ class FromPhysical(torch.autograd.Function):
     def backward(ctx, g):
         dtype, Cp = ctx.meta
         N, Cc, H, W = g.shape
-        out = empty((N, H, W, Cp), dtype, g.device).zero_()
-        to_physical(g, dtype, out=out)
-        return out, None
+        return cat_to_physical([g], dtype, out=empty((N, H, W, Cp), dtype, g.device)), None
 
 
 # ------------------------------------------------------------------------------------------
@@ -411,7 +399,6 @@ class ConvSpec:
         self.transposed, self.opad = transposed, opad
         self.norm, self.act = norm, act
         self._packed = {}
-        self._pending = {}                                        # key -> event of a side-stream pack not yet waited for
         # fp8 forward (networks.enable_fp8): `fp8` = run this layer's forward on e4m3 operands when the input carries an
         # e4m3 twin; `emit_q8` = the InstanceNorm pass of this layer also writes the e4m3 twin of its output
         self.fp8 = False
@@ -452,79 +439,13 @@ class ConvSpec:
         stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
-            ev = self._pending.pop(key, None) if self._pending else None
-            if ev is not None:                                    # packed on the side stream of this step (prepack_weights)
-                torch.cuda.current_stream().wait_event(ev)
             return hit[1]
-        # forward image written by FlatAdam's update kernel (optim.py): the layer's slice of the bf16 image IS the packed buffer
-        im = getattr(weight, "_p2phd_image", None) if which == 0 else None
-        if im is not None and im["stamp"] == stamp[:2] and d.w_layout == 1 and lib().p2phd_conv_fwd_image_is_master(C.byref(d)):
-            nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), 0)
-            buf = im["buf"][:nbytes // 2].view(torch.uint8)
-            buf._p2phd_is_image = True                            # never handed to the pack kernel as its output
-            self._packed[key] = (stamp, buf)
-            return buf
-        if _PREPACK["on"] and not _PREPACK["busy"]:
-            _PREPACK["list"].setdefault((id(self), which, d.dtype), (weakref.ref(self), weakref.ref(weight), which, d))
         nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
-        reuse = hit is not None and hit[1].numel() == nbytes and not getattr(hit[1], "_p2phd_is_image", False)
-        buf = hit[1] if reuse else empty((nbytes,), torch.uint8, weight.device)
+        buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
         w = _master_weight(weight, d)
         check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
-
-
-# Weight packs of a step on a side stream -- opt-in (P2PHD_PREPACK=1), measured SLOWER: 27.33 / 27.39 vs 26.80 / 26.84
-# ms/step at configs[1] B=32 over alternating graph-replayed runs.  The packed images (bf16 forward / input-gradient layouts
-# of every conv) depend only on the master weights, which are final when the step begins, and their ~75 small launches sit
-# in front of each layer's first use; `prepack_weights()` re-packs every image seen in the previous step on a side stream
-# at the start of the step, a layer's first use waits for its own pack only, `join_prepack()` joins the side stream
-# (inside the capture).  Same kernels, same operands, same numbers -- but a second branch in the replayed graph costs the
-# main chain more at its 75 cross-branch edges than the packs cost in line (the same finding as P2PHD_WGRAD_STREAM), and
-# a pack right in front of its conv is also what leaves the weights in the Infinity Cache for it (optim.FlatAdam._image).
-_PREPACK = {"on": os.environ.get("P2PHD_PREPACK", "0") == "1", "busy": False, "list": {}, "stream": None, "forked": False}
-
-
-def prepack_weights(device):
-    if not _PREPACK["on"] or not _PREPACK["list"] or torch.device(device).type != "cuda":
-        return
-    if _PREPACK["stream"] is None:
-        _PREPACK["stream"] = torch.cuda.Stream(device=device)
-    side, cur = _PREPACK["stream"], torch.cuda.current_stream()
-    side.wait_stream(cur)
-    _PREPACK["busy"] = True
-    try:
-        with torch.cuda.stream(side):
-            for rk, (rs, rw, which, d) in list(_PREPACK["list"].items()):
-                spec, weight = rs(), rw()
-                if spec is None or weight is None:                # the model is gone
-                    del _PREPACK["list"][rk]
-                    continue
-                key = (which, d.dtype)
-                hit = spec._packed.get(key)
-                stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
-                if hit is not None and hit[0] == stamp:
-                    continue
-                spec.packed(weight, which, d)
-                ev = torch.cuda.Event()
-                ev.record(side)
-                spec._pending[key] = ev
-    finally:
-        _PREPACK["busy"] = False
-    _PREPACK["forked"] = True
-
-
-def join_prepack():
-    """Make the current stream wait for every side-stream pack of this step; pending per-layer events are then moot."""
-    if not _PREPACK["forked"]:
-        return
-    torch.cuda.current_stream().wait_stream(_PREPACK["stream"])
-    for rs, _, _, _ in _PREPACK["list"].values():
-        spec = rs()
-        if spec is not None:
-            spec._pending.clear()
-    _PREPACK["forked"] = False
 
 
 def _master_weight(weight, d):
@@ -606,6 +527,7 @@ class ConvBlockFn(torch.autograd.Function):
                 raise _lib.P2PHDError("residual add is only fused behind InstanceNorm")
             out = y
         ctx.spec, ctx.d = spec, d
+        ctx.pair = _is_pair(x)
         ctx.skip_wgrad = _SKIP_WGRAD[0]
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -628,7 +550,7 @@ class ConvBlockFn(torch.autograd.Function):
         g = g.contiguous()
         if g.dtype != y.dtype:
             g = g.to(y.dtype)
-        rng = _bwd_range(d.N)
+        rng = _bwd_range(d.N, ctx.pair)
         x_full = x
         if rng is not None:
             # sample-range backward (see backward_on_samples): everything below runs on the sub-batch views
@@ -701,17 +623,8 @@ class ConvBlockFn(torch.autograd.Function):
             gw = weight.grad if direct else empty(tuple(weight.shape), torch.float32, y.device)
             wgrad = L.p2phd_conv_wgrad_acc if direct else L.p2phd_conv_wgrad
             dwd = d if w_layout(gw) == d.w_layout else spec.desc(d.N, d.H, d.W, y.dtype, w_layout(gw))   # layout of what is WRITTEN
-            if direct and _SIDE["on"] and not _GUARD["on"]:
-                side = _side_stream(y.device)
-                side.wait_stream(torch.cuda.current_stream())      # dy (and a bias gradient riding on its pass) are ready
-                with torch.cuda.stream(side):
-                    ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device, "side")
-                    check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
-                _SIDE["keep"].append((x, dy))
-                _SIDE["used"] = True
-            else:
-                ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device)
-                check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+            ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device)
+            check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
             if direct:
                 gw = gb = None
         gx_full = None
@@ -797,7 +710,7 @@ def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False)
     """`exclusive`: x is the output of another conv_block and this call is its ONLY consumer (see _bsum_enabled)."""
     if link is not None and residual is None:
         link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
-    out = ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive)
+    out = _tag_pair(ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive), x)
     if spec._q8_out is not None:                                    # e4m3 twin of this output for the next layer's fp8 forward
         out._p2phd_q8, spec._q8_out = spec._q8_out, None
     return out
@@ -816,6 +729,7 @@ class AvgPoolFn(torch.autograd.Function):
         y = empty((N, Ho, Wo, Cp), x.dtype, x.device)
         check(lib().p2phd_avgpool3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), N, H, W, channels, stream_ptr()), "avgpool_fwd")
         ctx.meta = (N, H, W, Cp, channels)
+        ctx.pair = _is_pair(x)
         return y
 
     @staticmethod
@@ -823,7 +737,7 @@ class AvgPoolFn(torch.autograd.Function):
         N, H, W, Cp, channels = ctx.meta
         g = g.contiguous()
         dx = empty((N, H, W, Cp), g.dtype, g.device)
-        rng = _bwd_range(N)
+        rng = _bwd_range(N, ctx.pair)
         if rng is not None:                                        # sample-range backward (backward_on_samples)
             lo, hi = rng
             check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
@@ -833,7 +747,7 @@ class AvgPoolFn(torch.autograd.Function):
 
 
 def avgpool(x, channels):
-    return AvgPoolFn.apply(x, channels)
+    return _tag_pair(AvgPoolFn.apply(x, channels), x)
 
 
 # ------------------------------------------------------------------------------------------

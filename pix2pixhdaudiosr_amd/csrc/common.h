@@ -42,10 +42,11 @@ int imdct4_fast(const float* spec, int64_t B, int64_t n_frames, int n_fft, const
 // agent-scope integer atomic, and the workgroup that drew the last ticket sums the rows in index order -- the result
 // does not depend on which workgroup finishes when.  The scratch is a `__device__` array of the code object (no
 // allocation in any entry point); one region per kernel family, so the families may run on different streams, but two
-// launches of the SAME family must be ordered (one compute stream per process, as everywhere in this library).
+// launches of the SAME family must be ordered: fold_scratch() remembers the region's last stream and refuses a launch on
+// another stream while that one still has work in flight (P2PHD_EINVAL instead of mixed partials).
 enum FoldRegion { FOLD_IN_BWD = 0, FOLD_COLSUM = 1, FOLD_ACT_DB = 2, FOLD_LOSS = 3, FOLD_GCONV = 4 };
 struct FoldScratch { float* part; unsigned* ticket; size_t floats; int tickets; };
-FoldScratch fold_scratch(int region);
+FoldScratch fold_scratch(int region, hipStream_t stream);   // part == nullptr: refused (error text set), see core.hip
 
 #ifdef __HIPCC__
 __device__ __forceinline__ void fold_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -48,7 +48,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPP = 4; };    // elements per 16-byte piece
 template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };
-// OCP e4m3 operands (v_mfma_f32_32x32x16_fp8_fp8): 16 per 16-byte piece; results leave as bf16
+// OCP e4m3 operands (block-scaled v_mfma_scale_f32_32x32x64_f8f6f4, unit scales): 16 per 16-byte piece; results leave as bf16
 struct fp8_t { unsigned char v; };
 template <> struct Elem<fp8_t> { static constexpr int EPP = 16; };
 template <typename T> struct OutOf { typedef T type; };
@@ -311,28 +311,11 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   // (fragment reads, LDS-DMA issue), so the matrix pipe already has work when the wave turns to them.
   auto mfma_one = [&](int buf, int i, int j) {
     if constexpr (sizeof(T) == 1) {
-#ifdef P2PHD_FP8_NOSCALE
-      // (round-2 form: two non-scaled K = 16 MFMAs per 16-byte fragment, the bf16 issue rate)
-      const uint4 av = af[buf][i], bw = bfr[buf][j];          // (composed from the dwords: pointer arithmetic on the fragment
-      const long a0 = (long)(((unsigned long)av.y << 32) | av.x), a1 = (long)(((unsigned long)av.w << 32) | av.z);   // arrays puts them in scratch)
-      const long b0 = (long)(((unsigned long)bw.y << 32) | bw.x), b1 = (long)(((unsigned long)bw.w << 32) | bw.z);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a0, b0, acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(a1, b1, acc[i][j], 0, 0, 0);
-#else
       // (block-scaled form: see mfma8 below)
       (void)buf; (void)i; (void)j;
-#endif
     } else if constexpr (sizeof(T) == 2) {
 #ifdef P2PHD_ABL_NOMFMA
       asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
-#elif defined(P2PHD_ABL_MFMA16)
-      // timing experiment only (wrong numbers): the same MACs as two v_mfma_f32_16x16x32_bf16 on the same registers
-      {
-        typedef __attribute__((ext_vector_type(4))) float f32x4_;
-        f32x4_* q = reinterpret_cast<f32x4_*>(&acc[i][j]);
-        q[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]), *reinterpret_cast<bf16x8*>(&bfr[buf][j]), q[0], 0, 0, 0);
-        q[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]), *reinterpret_cast<bf16x8*>(&bfr[buf][j]), q[1], 0, 0, 0);
-      }
 #else
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
                                                           *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);
@@ -350,15 +333,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   // consecutive k-steps side by side (any K permutation is fine as long as A and B share it).  Scales: e8m0 = 127 (1.0)
   // for every 32-element block -- the layer's scale is applied once in the epilogue, as before, so the numbers are those
   // of the non-scaled form.  A pair of k-steps (2q, 2q+1) is complete at the odd k-step, where its MR x NR MFMAs go out
-  // (H1 = all of them).  -DP2PHD_FP8_SPREAD issues only the first half there and the second half at the following even
-  // k-step (for the pair (2,3): k-step 0 of the NEXT slab; flushed after the loop), so that every k-step has matrix work
-  // to hide its fragment reads behind: measured SLOWER (trunk 108 vs 103 us, cfg5 trunk 183 vs 172 us; 256 VGPRs against
-  // 239) -- the two waves of a SIMD already fill each other's gaps.  Position p of k-step ks:
-#ifdef P2PHD_FP8_SPREAD
-  constexpr int NT8 = MR * NR, H1 = (NT8 + 1) / 2;
-#else
+  // (H1 = all of them; spreading them over both k-steps of a pair measured slower).  Position p of k-step ks:
   constexpr int NT8 = MR * NR, H1 = NT8;
-#endif
   auto mfma8 = [&](int ks, int p) {
     if constexpr (sizeof(T) == 1) {
       const int idx = (ks & 1) ? p : H1 + p;
@@ -373,11 +349,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       }
     }
   };
-#ifdef P2PHD_FP8_NOSCALE
-  constexpr bool kScaled = false;
-#else
   constexpr bool kScaled = sizeof(T) == 1;
-#endif
   if constexpr (kScaled) {                                     // (the first slab's k-step 0 multiplies zeros)
 #pragma unroll
     for (int i = 0; i < MR; ++i) af[2][i] = af[3][i] = make_uint4(0, 0, 0, 0);
@@ -410,9 +382,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0u, 0, 0);
 
-#ifdef P2PHD_PRIO
-  if (wave >= (WGM * WGN) / 2) __builtin_amdgcn_s_setprio(1);  // static priority for the younger half (same guide, item 4)
-#endif
   int cur = 0;
   bool pend = false;                              // second half of a tile's pieces still to be issued (at k-step 0)
   int pend_slot = 0, pend_tile = 0;
@@ -461,26 +430,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       if constexpr (kScaled) mfma8(ks, 1); else if constexpr (MR * NR > 1) mfma_one(buf, 1 / NR, 1 % NR);
       __builtin_amdgcn_sched_barrier(0);
 #ifndef P2PHD_ABL_NODMA
-#ifdef P2PHD_STAGGER
-      // Stagger (MI355X_MICROARCH.md, two waves per SIMD, item 9): the SIMD partners (waves w and w + 4) run the same
-      // program in lockstep, so both would issue their LDS-DMA pieces -- 100-185 cycles of VMEM issue each -- in the
-      // same MFMA gaps and leave the matrix pipe idle together.  Waves 0-3 issue the whole next tile right behind the
-      // barrier (k-step 3), waves 4-7 one k-step later (k-step 0 of the next slab): one partner always has MFMAs to issue.
-      if (ks == 0 && pend) {
-#pragma unroll
-        for (int j = 0; j < NLOADS; ++j) issue_piece(pend_slot, pend_tile, j);
-        pend = false;
-      }
-      if (ks == 3 && issue_new) {
-        prepare();
-        if (wave < (WGM * WGN) / 2) {
-#pragma unroll
-          for (int j = 0; j < NLOADS; ++j) issue_piece(cur, s_begin + s + NSTAGE, j);
-        } else {
-          pend = true; pend_slot = cur; pend_tile = s_begin + s + NSTAGE;
-        }
-      }
-#else
       if (ks == 0 && pend) {
 #pragma unroll
         for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, pend_tile, j);
@@ -493,20 +442,13 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         pend = true; pend_slot = cur; pend_tile = s_begin + s + NSTAGE;
       }
 #endif
-#endif
       __builtin_amdgcn_sched_barrier(0);
-#ifdef P2PHD_MFMAPRIO
-      __builtin_amdgcn_s_setprio(1);                             // (guide T5: priority around the MFMA cluster; measured null here)
-#endif
       if constexpr (kScaled) {
 #pragma unroll
         for (int p = 2; p < H1; ++p) mfma8(ks, p);
       } else {
         mfma_rest(buf, MR * NR > 1 ? 2 : 1);
       }
-#ifdef P2PHD_MFMAPRIO
-      __builtin_amdgcn_s_setprio(0);
-#endif
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifdef P2PHD_PROBE
@@ -831,8 +773,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #endif
 }
 
-#include "gconv_persist.inc"
-
 // ------------------------------------------------------------------------------------------------------
 // weight gradient:  dWp[split][m][t*Cg + c] = sum_{p in split} rows[p][m] * gather[pix(p,t)][c]
 //   rows   : [N*Hg*Wg][Cp_r]   the tensor on the pixel grid (dy for Conv2d, x for ConvTranspose2d)
@@ -1149,22 +1089,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MI * NI > 1) mfma_one(buf, 1 / NI, 1 % NI);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef P2PHD_STAGGER
-        if (sub == 0 && pend) {                                   // (see gconv_kernel: waves 4-7 issue their pieces one sub-step later)
-#pragma unroll
-          for (int j = 0; j < NLOADS; ++j) issue_piece(pend_slot, j);
-          pend = false;
-        }
-        if (sub == NSUB - 1 && issue_new) {
-          prepare();
-          if (wave < 4) {
-#pragma unroll
-            for (int j = 0; j < NLOADS; ++j) issue_piece(cur, j);
-          } else {
-            pend = true; pend_slot = cur;
-          }
-        }
-#else
         if (sub == 0 && pend) {
 #pragma unroll
           for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, j);
@@ -1176,7 +1100,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
           for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, j);
           pend = true; pend_slot = cur;
         }
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -1830,26 +1753,9 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   d.grid_m = mtiles;
   d.sk_first = TT; d.sk_tail = 1; d.sk_parts = 1; d.sk_steps = 0; d.sk_part = nullptr; d.sk_ticket = nullptr;
   int wgs = TT;
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0; hipDeviceProp_t prop;
-    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
-  // Persistent form (gconv_persist.inc): one workgroup per CU walks its tiles and fills the next tile's ring under the
-  // current epilogue.  Forward-type launches of many tiles on the two tile shapes that carry the short-K / medium-K layers.
-  constexpr bool kPersistCfg = sizeof(T) == 2 && BM == 256 && MR * NR <= 6 && BN == 128 && NSTAGE == 3;   // (256 x 192 on its 2-slot ring: built, bit-exact, 4-7 % SLOWER -- one prefetched stage is not enough)
-  if constexpr (kPersistCfg) {
-    const size_t lds_p = (size_t)tab + BM * 8 + (size_t)NSTAGE * STAGE;
-    if (p2phd::g_opt_gconv_persist != 0 && d.act != P2PHD_ACT_TANH && d.bs_out == nullptr && d.as_x == nullptr && addend == nullptr && TT >= 2 * cus &&
-        d.KK / (8 * Elem<T>::EPP) >= NSTAGE && lds_p <= 160 * 1024) {
-      auto pk = gconv_pkernel<T, BM, BN, MR, NR, NSTAGE>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p);
-      typedef typename OutOf<T>::type TOp;
-      hipLaunchKernelGGL(pk, dim3((unsigned)cus), dim3((BM / (MR * 32)) * (BN / (NR * 32)) * 64), lds_p, st, d, (const T*)in, (const T*)wp, bias,
-                         (TOp*)out, stats);
-      return p2phd::check_launch("gconv(persistent)");
-    }
-  }
+  // CUs this launch can occupy: the device's count (cached per device), or what the caller states with
+  // p2phd_set_option("cus", n) when the step runs on a CU-masked stream (opt.comm_cus leaves some to the RCCL kernels)
+  const int cus = p2phd::g_opt_cus > 0 ? p2phd::g_opt_cus : p2phd::device_cus();
   if (p2phd::g_opt_splitk_tail != 0) {
     const int nsteps = d.KK / (8 * Elem<T>::EPP);
     const int full = TT / cus * cus, tail = TT - full;
@@ -1878,9 +1784,9 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
       best = 0.0;
     }
     if (bestP >= 2 && best < 0.95 * now) {
-      const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_GCONV);
+      const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_GCONV, st);
       const int steps = (nsteps + bestP - 1) / bestP;
-      if (fs.part != nullptr && (size_t)tail * bestP * BM * BN <= fs.floats && tail <= fs.tickets) {
+      if (fs.part != nullptr && (size_t)tail * bestP * BM * BN <= fs.floats && tail <= fs.tickets) {   // (more tail tiles than tickets -- chips beyond 256 CUs -- simply run unsplit)
         d.sk_first = full; d.sk_tail = tail; d.sk_parts = bestP; d.sk_steps = steps; d.sk_part = fs.part; d.sk_ticket = fs.ticket;
         wgs = full + tail * bestP;
       }
@@ -2158,12 +2064,6 @@ int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int 
   return check_launch("pack_weights(merged)");
 }
 
-// true when launch_pack would be nothing but a cast of the K-major master rows (no K tail, no padding rows): the bf16 image
-// FlatAdam's update kernel writes beside the f32 master weights IS the packed forward image (p2phd_conv_fwd_image_is_master)
-bool pack_is_master_cast(const GDesc& d, const WMap& m, int rows_pad) {
-  return d.cls_cp == 0 && kmajor_dense_map(d, m) && d.KK % 4 == 0 && d.KK == d.nth * d.ntw * m.inner && rows_pad == m.rows;
-}
-
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st) {
   if (rows_pad <= 0) return P2PHD_OK;
   if (kmajor_dense_map(d, m) && d.KK % 4 == 0) {
@@ -2254,8 +2154,9 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, in
   while (cpg * 2 <= cpr && cpg * 2 <= 64) cpg *= 2;
   const int R = 256 / cpg;
   const int ygroups = (cpr + cpg - 1) / cpg;
-  const FoldScratch fs = fold_scratch(FOLD_COLSUM);
-  P2PHD_REQUIRE(fs.part != nullptr && ygroups <= fs.tickets, "colsum: reduction scratch unavailable or too many channels (%d)", Cp);
+  const FoldScratch fs = fold_scratch(FOLD_COLSUM, st);
+  if (fs.part == nullptr) return P2PHD_EINVAL;                   // (refused: error text set by fold_scratch)
+  P2PHD_REQUIRE(ygroups <= fs.tickets, "colsum: too many channels (%d)", Cp);
   const long rows_max = (long)(fs.floats / ((size_t)ygroups * cpg * epp));   // partial rows per column group
   P2PHD_REQUIRE(rows_max >= 1, "colsum: too many channels for the reduction scratch");
   const int xblocks = (int)std::max<long>(1, std::min<long>(std::min<long>((P + R * 32 - 1) / (R * 32), 512), rows_max));

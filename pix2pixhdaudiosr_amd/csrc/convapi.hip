@@ -290,14 +290,6 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   return n * elem_size(c->dtype);
 }
 
-extern "C" int p2phd_conv_fwd_image_is_master(const p2phd_conv_desc* c) {
-  if (c == nullptr || check_desc(c) != P2PHD_OK || c->w_layout != 1 || c->dtype != P2PHD_BF16) return 0;
-  if (c7_fast_shape(c) || c7_out_shape(c)) return 0;
-  std::vector<Plan> plans; WMap m;
-  make_plans(c, 0, plans, &m);
-  return (plans.size() == 1 && plans[0].w_off == 0 && pack_is_master_cast(plans[0].d, m, plans[0].rows_pad)) ? 1 : 0;
-}
-
 extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w, void* packed, void* stream) {
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(which == 0 || which == 1, "pack_weights: which must be 0 (forward) or 1 (input gradient)");
@@ -419,7 +411,7 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
 }
 
 // ------------------------------------------------------------------------------------------------------
-// fp8 forward (BASELINE configs[4]: "bf16 + fp8 MFMA conv weights"): OCP e4m3 operands on v_mfma_f32_32x32x16_fp8_fp8 for
+// fp8 forward (BASELINE configs[4]: "bf16 + fp8 MFMA conv weights"): OCP e4m3 operands on the block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales) for
 // the wide stride-1 layers (residual trunk, discriminator 256 -> 512), fp32 master weights and the bf16 backward unchanged.
 // Weights are quantised per layer (scale = amax / 448, found on the device: no host synchronisation), activations arrive
 // already quantised (scale 1: they are InstanceNorm outputs) from p2phd_instnorm_act_fwd_q8.

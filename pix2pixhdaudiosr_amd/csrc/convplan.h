@@ -67,8 +67,8 @@ extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
 extern int g_opt_c7_generic;
 extern int g_opt_splitk_tail;       // 0: every tile is one workgroup, 1 (default): split-K tail where the cost model says so, 2: wherever possible (tests)
-extern int g_opt_gconv_persist;     // 1: forward-type launches of >= 2 tiles per CU on 256 x 128 tiles take the persistent kernel (gconv_persist.inc);
-                                    // default 0: bit-exact but at break-even so far
+extern int g_opt_cus;               // > 0: CUs a conv launch may count on (a CU-masked compute stream); 0 = all of the device's
+int device_cus();                   // multiProcessorCount of the current device, cached per device
 extern int g_opt_reflect_generic;   // 1: reflect-padded 3x3 input gradients on the padded grid + fold (the general form)
 extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 
@@ -120,7 +120,6 @@ int launch_wgrad(const GDesc& d, const WMap& m, int dtype, const void* rows, int
 int launch_pack_merged(const GDesc& d, int dtype, const float* w, void* wp, int rows_pad, int K, int C, int R, int S, int pad,
                        long s_k, long s_c, hipStream_t st);
 int launch_pack(const GDesc& d, const WMap& m, int dtype, const float* w, void* wp, int rows_pad, hipStream_t st);
-bool pack_is_master_cast(const GDesc& d, const WMap& m, int rows_pad);
 bool gconv_plain_launch_takes_256x256(const GDesc& d, int dtype);
 int launch_reflect_expand(int dtype, const void* dy, void* e_out, int N, int H, int W, int Cp, hipStream_t st);
 int launch_reflect_fold(int dtype, const void* dxp, const void* addend, void* dx, int N, int H, int W, int Cp, int P,

@@ -13,7 +13,18 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace p2phd
 
-namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_gconv_persist = 0; }
+namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
+int device_cus() {
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cached[dev] == 0) {
+    hipDeviceProp_t prop;
+    cached[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+  }
+  return cached[dev];
+}
+}
 
 // scratch of the fixed-order cross-workgroup reductions (common.h): zero-initialised with the code object
 namespace {
@@ -23,24 +34,67 @@ __device__ float g_fold_part[(size_t(22) << 20) + 4096];      // 88 MiB, zero-in
 __device__ unsigned g_fold_ticket[2048 + 1024 + 16 + 256];
 }  // namespace
 namespace p2phd {
-FoldScratch fold_scratch(int region) {
-  static float* parts[64] = {};
-  static unsigned* tickets[64] = {};
+namespace {
+struct FoldDev { float* part = nullptr; unsigned* ticket = nullptr; hipStream_t last[5] = {}; bool used[5] = {}; };
+FoldDev g_fold_dev[64];
+FoldDev* fold_dev() {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return FoldScratch{nullptr, nullptr, 0, 0};
-  if (parts[dev] == nullptr) {                                  // (the symbol has one address per device)
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  FoldDev& f = g_fold_dev[dev];
+  if (f.part == nullptr) {                                      // (the symbol has one address per device)
     void* p = nullptr; void* t = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fold_part)) != hipSuccess || hipGetSymbolAddress(&t, HIP_SYMBOL(g_fold_ticket)) != hipSuccess)
-      return FoldScratch{nullptr, nullptr, 0, 0};
-    parts[dev] = static_cast<float*>(p); tickets[dev] = static_cast<unsigned*>(t);
+      return nullptr;
+    f.part = static_cast<float*>(p); f.ticket = static_cast<unsigned*>(t);
   }
-  float* part = parts[dev];
-  unsigned* ticket = tickets[dev];
+  return &f;
+}
+}  // namespace
+
+// The region's partial rows and tickets, for a launch on `stream`.  One region serves ONE stream at a time: when a launch
+// arrives on another stream than the region's last one, that stream must have drained (hipStreamQuery) -- the caller ordered
+// them with an event / a synchronisation, as torch's stream switches and graph captures do -- else two launches of one kernel
+// family could mix their partials, and the call is refused (part == nullptr, error text set) instead of computing garbage.
+FoldScratch fold_scratch(int region, hipStream_t stream) {
+  FoldDev* f = fold_dev();
+  if (f == nullptr || region < 0 || region >= 5) { set_error("reduction scratch unavailable"); return FoldScratch{nullptr, nullptr, 0, 0}; }
+  if (f->used[region] && f->last[region] != stream) {
+    // A stream under capture enqueues nothing: its launches run when the graph is replayed, in graph order, and a capture
+    // is entered behind a synchronisation; querying other streams from a capturing thread can invalidate the capture.
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool now_capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    cs = hipStreamCaptureStatusNone;
+    const bool prev_capturing = !now_capturing && hipStreamIsCapturing(f->last[region], &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (!now_capturing && !prev_capturing) {
+      const hipError_t q = hipStreamQuery(f->last[region]);
+      if (q == hipErrorNotReady) {
+        set_error("two streams use reduction-scratch region %d at once: a launch of this kernel family is still in flight on "
+                  "another stream (order the streams, or keep one compute stream per process: include/p2phd.h, \"Streams\")", region);
+        return FoldScratch{nullptr, nullptr, 0, 0};
+      }
+      (void)hipGetLastError();                                  // (a stale stream handle: nothing of it can be in flight)
+    }
+  }
+  f->used[region] = true;
+  f->last[region] = stream;
   size_t fo = 0; int to = 0;
   for (int r = 0; r < region; ++r) { fo += kFoldFloats[r]; to += kFoldTickets[r]; }
-  return FoldScratch{part + fo, ticket + to, kFoldFloats[region], kFoldTickets[region]};
+  return FoldScratch{f->part + fo, f->ticket + to, kFoldFloats[region], kFoldTickets[region]};
 }
 }  // namespace p2phd
+
+// Re-arms every arrival ticket of the fixed-order reductions (an aborted or faulted launch may have left one non-zero, which
+// would make every later launch of that kernel family fold at the wrong moment): a 13 KB memset on `stream`; the Python
+// mirror issues it once per training step beside its own per-step memset (_ops.begin_step).
+extern "C" int p2phd_reduction_reset(void* stream) {
+  void* t = nullptr;
+  if (hipGetSymbolAddress(&t, HIP_SYMBOL(g_fold_ticket)) != hipSuccess) { p2phd::set_error("reduction_reset: no device symbol"); return P2PHD_ELAUNCH; }
+  if (hipMemsetAsync(t, 0, sizeof(unsigned) * (2048 + 1024 + 16 + 256), (hipStream_t)stream) != hipSuccess) {
+    p2phd::set_error("reduction_reset: memset failed");
+    return P2PHD_ELAUNCH;
+  }
+  return P2PHD_OK;
+}
 
 extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "gconv_bm") && (value == 0 || value == 128 || value == 192 || value == 256 || value == 258 || value == 512)) { p2phd::g_opt_gconv_bm = value; return P2PHD_OK; }
@@ -48,7 +102,7 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "reflect_generic") && (value == 0 || value == 1)) { p2phd::g_opt_reflect_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_iters") && value >= 0 && value <= 8) { p2phd::g_opt_mdct_iters = value; return P2PHD_OK; }
   if (name && !strcmp(name, "splitk_tail") && value >= 0 && value <= 2) { p2phd::g_opt_splitk_tail = value; return P2PHD_OK; }
-  if (name && !strcmp(name, "gconv_persist") && (value == 0 || value == 1)) { p2phd::g_opt_gconv_persist = value; return P2PHD_OK; }
+  if (name && !strcmp(name, "cus") && value >= 0 && value <= 4096) { p2phd::g_opt_cus = value; return P2PHD_OK; }
   if (name && !strcmp(name, "c7_abl")) { p2phd::g_opt_c7_abl = value; return P2PHD_OK; }
   if (name && !strcmp(name, "c7_generic") && (value == 0 || value == 1)) { p2phd::g_opt_c7_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_generic") && (value == 0 || value == 1)) { p2phd::g_opt_mdct_generic = value; return P2PHD_OK; }

@@ -135,13 +135,10 @@ inline int grid_for(long work, int cap = 2048) { return (int)std::max<long>(1, s
 
 // Device-resident step counter and learning rate: the launch arguments no longer change from step to step, so a whole
 // training step (this kernel included) can be captured once into a HIP graph and replayed.
-// SHADOW: also leaves the updated weights as bf16 at the same element offsets (the packed forward image of the layers whose
-// master weights are K-major: one 8-byte store per four weights instead of a pack launch per layer and step).
-template <bool SHADOW>
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, const float* __restrict__ lr_dev,
                                                        const long long* __restrict__ step_dev, float b1, float b2, float eps,
-                                                       float gscale, __bf16* __restrict__ shadow) {
+                                                       float gscale) {
   const double t = (double)(*step_dev + 1);
   const float lr = *lr_dev;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
@@ -172,18 +169,12 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
         __builtin_nontemporal_store(mo, reinterpret_cast<f4v*>(m + e));
         __builtin_nontemporal_store(vo, reinterpret_cast<f4v*>(v + e));
       }
-      if constexpr (SHADOW) {
-        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_;
-        const bf16x4_ sb = {(__bf16)pa[0], (__bf16)pa[1], (__bf16)pa[2], (__bf16)pa[3]};
-        *reinterpret_cast<bf16x4_*>(shadow + e) = sb;
-      }
     } else {
       for (long i = e; i < n; ++i) {
         const float gr = g[i] * gscale;
         m[i] = b1 * m[i] + (1.f - b1) * gr;
         v[i] = b2 * v[i] + (1.f - b2) * gr * gr;
         p[i] -= (lr / bc1) * m[i] / (sqrtf(v[i]) / bc2_sqrt + eps);
-        if constexpr (SHADOW) shadow[i] = (__bf16)p[i];
       }
     }
   }
@@ -200,8 +191,8 @@ extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b,
   if (P == 0) return P2PHD_OK;
   const int Cp = (C + 7) & ~7;
   hipStream_t st = (hipStream_t)stream;
-  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_LOSS);
-  P2PHD_REQUIRE(fs.part != nullptr && fs.floats >= 1024, "loss_fwd: reduction scratch unavailable");
+  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_LOSS, st);
+  if (fs.part == nullptr) return P2PHD_EINVAL;                   // (refused: error text set by fold_scratch)
   if (dtype == P2PHD_BF16)
     hipLaunchKernelGGL(loss_fwd_kernel<bf16_t>, dim3(grid_for(P * Cp / 8, 1024)), dim3(256), 0, st, kind, (const bf16_t*)a, (const bf16_t*)b, target, (long)P, C, Cp, coeff, out, fs.part, fs.ticket);
   else if (dtype == P2PHD_F32)
@@ -238,36 +229,17 @@ extern "C" int p2phd_adam_step(float* params, const float* grads, float* exp_avg
   return p2phd::check_launch("adam_step");
 }
 
-static int adam_step_dev_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                              const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
-                              float grad_scale, void* shadow, void* stream) {
+extern "C" int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
+                                   float grad_scale, void* stream) {
   P2PHD_REQUIRE(n >= 0, "adam_step_dev: negative size");
   P2PHD_REQUIRE(lr_dev && step_dev, "adam_step_dev: null state pointer");
   if (n > 0) {
     P2PHD_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step_dev: null pointer");
     const dim3 grid(grid_for((n + 3) / 4, 4096));
-    if (shadow != nullptr) {
-      P2PHD_REQUIRE((uintptr_t)shadow % 8 == 0, "adam_step_dev: the bf16 image must be 8-byte aligned");
-      hipLaunchKernelGGL(adam_dev_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
-                         reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale, reinterpret_cast<__bf16*>(shadow));
-    } else {
-      hipLaunchKernelGGL(adam_dev_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
-                         reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale, (__bf16*)nullptr);
-    }
+    hipLaunchKernelGGL(adam_dev_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale);
   }
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step_dev));
   return p2phd::check_launch("adam_step_dev");
-}
-
-extern "C" int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                   const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
-                                   float grad_scale, void* stream) {
-  return adam_step_dev_impl(params, grads, exp_avg, exp_avg_sq, n, lr_dev, step_dev, beta1, beta2, eps, grad_scale, nullptr, stream);
-}
-
-extern "C" int p2phd_adam_step_dev_image(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                         const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
-                                         float grad_scale, void* image_bf16, void* stream) {
-  P2PHD_REQUIRE(image_bf16 != nullptr, "adam_step_dev_image: null image pointer");
-  return adam_step_dev_impl(params, grads, exp_avg, exp_avg_sq, n, lr_dev, step_dev, beta1, beta2, eps, grad_scale, image_bf16, stream);
 }

@@ -579,15 +579,55 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
   }
 }
 
+// dst f32 [N,C,HW] <- channels [ch_off, ch_off+C) of src [N,HW,Cp]: a thread owns one 16-byte piece of a pixel (one load) and
+// scatters its channels to their planes (consecutive threads = consecutive pixels when a pixel is one piece: coalesced)
 template <typename T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, float* __restrict__ dst, int N, int C, long HW, int Cp, int ch_off) {
-  const long total = (long)N * C * HW;
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long total = (long)N * HW * cpr;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const long p = e % HW;
     const long r = e / HW;
-    const int c = (int)(r % C);
-    const long n = r / C;
-    dst[e] = to_f(src[((size_t)n * HW + p) * Cp + ch_off + c]);
+    const int pc = (int)(r % cpr);
+    const long n = r / cpr;
+    const int c_lo = pc * EPP - ch_off;                         // destination channel of the piece's first element
+    if (c_lo + EPP <= 0 || c_lo >= C) continue;
+    const uint4 v = *reinterpret_cast<const uint4*>(src + ((size_t)n * HW + p) * Cp + pc * EPP);
+    const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = c_lo + k;
+      if (c >= 0 && c < C) dst[((size_t)n * C + c) * HW + p] = to_f(vv[k]);
+    }
+  }
+}
+
+// Up to four f32 [N,C_i,HW] tensors concatenated along channels -> dst [N,HW,Cp], pad channels written as zeros: every
+// 16-byte piece of dst is written exactly once (no memset of the padded tensor, one launch for a concatenation).
+struct CatSrc { const float* src[4]; int c0[5]; };               // source i holds channels [c0[i], c0[i+1])
+template <typename T>
+__global__ void nchw_cat_to_nhwc_kernel(CatSrc cs, int nsrc, T* __restrict__ dst, int N, long HW, int Cp) {
+  constexpr int EPP = Elem<T>::EPP;
+  const int cpr = Cp / EPP;
+  const long total = (long)N * HW * cpr;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const long p = e % HW;
+    const long r = e / HW;
+    const int pc = (int)(r % cpr);
+    const long n = r / cpr;
+    uint4 ov;
+    T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+    for (int k = 0; k < EPP; ++k) {
+      const int c = pc * EPP + k;
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nsrc && c >= cs.c0[i] && c < cs.c0[i + 1]) v = cs.src[i][((size_t)n * (cs.c0[i + 1] - cs.c0[i]) + (c - cs.c0[i])) * HW + p];
+      oo[k] = from_f<T>(v);
+    }
+    *reinterpret_cast<uint4*>(dst + ((size_t)n * HW + p) * Cp + pc * EPP) = ov;
   }
 }
 
@@ -783,8 +823,8 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   dim3 grid(stationary_grid(HW, Cp / epp, N), N);
   if (!sums_given) {
     // partial table of the fixed-order reduction: one row of 2 * Cp floats per workgroup, one ticket per sample
-    const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_IN_BWD);
-    P2PHD_REQUIRE(fs.part != nullptr, "instnorm_act_bwd: reduction scratch unavailable");
+    const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_IN_BWD, st);
+    if (fs.part == nullptr) return P2PHD_EINVAL;                 // (refused: error text set by fold_scratch)
     P2PHD_REQUIRE(N <= fs.tickets, "instnorm_act_bwd: at most %d samples per call", fs.tickets);
     const int unit = stationary_unit(Cp / epp);
     const long rows_max = (long)(fs.floats / (2 * (size_t)Cp * (size_t)N));
@@ -875,14 +915,34 @@ extern "C" int p2phd_nchw_to_nhwc(int dtype, const float* src, void* dst, int N,
   return p2phd::check_launch("nchw_to_nhwc");
 }
 
-extern "C" int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream) {
-  if ((long)N * C * HW == 0) return P2PHD_OK;
-  P2PHD_REQUIRE(src && dst && ch_off >= 0 && ch_off + C <= Cp, "nhwc_to_nchw: bad arguments");
-  const long work = (long)N * C * HW;
+extern "C" int p2phd_nchw_cat_to_nhwc(int dtype, const float* const* srcs, const int* chans, int nsrc, void* dst, int N, int64_t HW,
+                                      int Cp, void* stream) {
+  P2PHD_REQUIRE(srcs && chans && dst && nsrc >= 1 && nsrc <= 4 && Cp % 8 == 0, "nchw_cat_to_nhwc: bad arguments");
+  CatSrc cs{};
+  int c = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    P2PHD_REQUIRE(srcs[i] != nullptr && chans[i] >= 1, "nchw_cat_to_nhwc: bad source %d", i);
+    cs.src[i] = srcs[i]; cs.c0[i] = c; c += chans[i];
+  }
+  cs.c0[nsrc] = c;
+  for (int i = nsrc; i < 4; ++i) { cs.src[i] = nullptr; cs.c0[i + 1] = c; }
+  P2PHD_REQUIRE(c <= Cp, "nchw_cat_to_nhwc: %d channels do not fit a pitch of %d", c, Cp);
+  if ((long)N * HW == 0) return P2PHD_OK;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for(work)), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, (long)HW, Cp, ch_off),
-             hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for(work)), dim3(256), 0, st, (const float*)src, dst, N, C, (long)HW, Cp, ch_off),
+             hipLaunchKernelGGL(nchw_cat_to_nhwc_kernel<bf16_t>, dim3(grid_for((long)N * HW * (Cp / 8))), dim3(256), 0, st, cs, nsrc, (bf16_t*)dst, N, (long)HW, Cp),
+             hipLaunchKernelGGL(nchw_cat_to_nhwc_kernel<float>, dim3(grid_for((long)N * HW * (Cp / 4))), dim3(256), 0, st, cs, nsrc, (float*)dst, N, (long)HW, Cp),
+             "nchw_cat_to_nhwc");
+  return p2phd::check_launch("nchw_cat_to_nhwc");
+}
+
+extern "C" int p2phd_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int64_t HW, int Cp, int ch_off, void* stream) {
+  if ((long)N * C * HW == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(src && dst && ch_off >= 0 && ch_off + C <= Cp && Cp % 8 == 0, "nhwc_to_nchw: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(grid_for((long)N * HW * (Cp / 8))), dim3(256), 0, st, (const bf16_t*)src, dst, N, C, (long)HW, Cp, ch_off),
+             hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(grid_for((long)N * HW * (Cp / 4))), dim3(256), 0, st, (const float*)src, dst, N, C, (long)HW, Cp, ch_off),
              "nhwc_to_nchw");
   return p2phd::check_launch("nhwc_to_nchw");
 }
@@ -901,8 +961,8 @@ extern "C" int p2phd_act_bwd_db(int dtype, const void* g, const void* a, void* d
   P2PHD_REQUIRE(g && a && dx, "act_bwd_db: null pointer");
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
   // bias gradient with a REAL value (no normalisation behind the conv): summed in a fixed order, see in_act_bwd_reduce_kernel
-  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_ACT_DB);
-  P2PHD_REQUIRE(fs.part != nullptr, "act_bwd_db: reduction scratch unavailable");
+  const p2phd::FoldScratch fs = p2phd::fold_scratch(p2phd::FOLD_ACT_DB, st);
+  if (fs.part == nullptr) return P2PHD_EINVAL;                   // (refused: error text set by fold_scratch)
   const int unit = stationary_unit(Cp / epp);
   const long rows_max = (long)(fs.floats / (size_t)Cp);
   P2PHD_REQUIRE(rows_max >= unit, "act_bwd_db: too many channels for the reduction scratch");

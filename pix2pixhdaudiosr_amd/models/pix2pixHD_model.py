@@ -312,7 +312,6 @@ class Pix2PixHDModel(BaseModel):
         and the attached pass compute identical values, only their backward differs, so `train_step` walks the one
         retained graph twice (G loss without D weight gradients, then D loss restricted to D's parameters)."""
         _ops.begin_step(self.device)                               # one memset for every statistics / loss accumulator
-        _ops.prepack_weights(self.device)                          # this step's weight images, on a side stream
         lr_spectro, lr_pha, hr_spectro, hr_pha, _, _, hr_norm_param, lr_norm_param = \
             self.encode_input(lr_audio, None, hr_audio, None, noise=noise)
 
@@ -333,7 +332,7 @@ class Pix2PixHDModel(BaseModel):
             # every value equals the two-pass result.  The generator-loss backward then runs on the fake half only
             # (_ops.backward_on_samples in _g_stages), the discriminator-loss backward on the whole batch.
             B = int(lr_spectro.shape[0])
-            pred = self.netD.forward_physical(_ops.ToPhysicalPair.apply(self.compute_dtype, lr_spectro, hr_spectro, sr_result),
+            pred = self.netD.forward_physical(_ops.to_physical_pair(self.compute_dtype, lr_spectro, hr_spectro, sr_result),
                                               exclusive=True)
             self._pair_batch = 2 * B
             loss_D_real = loss_D_fake = loss_G_GAN = 0
@@ -387,7 +386,6 @@ class Pix2PixHDModel(BaseModel):
         # visuals are fetched lazily (no device->host copy in the step)
         self._visual = (lr_spectro, sr_result.detach(), hr_spectro, hr_pha)
         _ops.end_arena(self.device)
-        _ops.join_prepack()
         return self.loss_filter(loss_G_GAN, loss_G_GAN_Feat, 0, loss_G_match, 0, 0, 0, loss_D_real, loss_D_fake), sr_result
 
     def forward(self, lr_audio, inst, hr_audio, feat, infer=False, noise=None):
@@ -453,7 +451,7 @@ class Pix2PixHDModel(BaseModel):
         total = optG._total
         if not cuts:
             def whole():
-                with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream(), self._fake_half():
+                with _ops.backward_without_weight_grads(optD._params), self._fake_half():
                     loss_G.backward(inputs=list(optG._params), retain_graph=True)
             return [(whole, (0, total))]
         state = {}
@@ -462,21 +460,19 @@ class Pix2PixHDModel(BaseModel):
         anchors = list(getattr(self.netG, 'staged_head_anchors', lambda: [])())
 
         def head():
-            with _ops.backward_without_weight_grads(optD._params), _ops.wgrad_side_stream(), self._fake_half():
+            with _ops.backward_without_weight_grads(optD._params), self._fake_half():
                 # (anchors: parameters of a branch parallel to the last cut -- the LocalEnhancer's head; their gradient
                 # arrives in the flat buffer like every other one, autograd itself gets None for them)
                 state['g'] = torch.autograd.grad(loss_G, [cuts[-1]] + anchors, retain_graph=True, allow_unused=True)[0]
         stages.append((head, (offs[-1], total)))
         for i in range(len(cuts) - 2, -1, -1):
             def mid(i=i):
-                with _ops.wgrad_side_stream():
-                    (state['g'],) = torch.autograd.grad(cuts[i + 1], [cuts[i]], grad_outputs=state['g'], retain_graph=True)
+                (state['g'],) = torch.autograd.grad(cuts[i + 1], [cuts[i]], grad_outputs=state['g'], retain_graph=True)
             stages.append((mid, (offs[i], offs[i + 1])))
         first_params = [p for p, o in zip(optG._params, optG._offs) if o < offs[0]]
 
         def tail():
-            with _ops.wgrad_side_stream():
-                cuts[0].backward(gradient=state['g'], inputs=first_params, retain_graph=True)
+            cuts[0].backward(gradient=state['g'], inputs=first_params, retain_graph=True)
             state.clear()
         stages.append((tail, (0, offs[0])))
         return stages
@@ -495,7 +491,7 @@ class Pix2PixHDModel(BaseModel):
         """Backward of the discriminator loss through the graph phase A kept."""
         loss_D, self._loss_D = self._loss_D, None
         firsts = [self.netD._scale_steps(d)[0][0].spec for d in range(self.opt.num_D)]
-        with _ops.backward_without_input_grads(firsts), _ops.wgrad_side_stream():   # no gradient towards the generator in this pass
+        with _ops.backward_without_input_grads(firsts):   # no gradient towards the generator in this pass
             loss_D.backward(inputs=list(self.optimizer_D._params))
 
     # opt.comm_cus = N > 0 (data parallel only makes sense): the step runs on a stream whose CU mask leaves N CUs to the
@@ -510,8 +506,14 @@ class Pix2PixHDModel(BaseModel):
             st = self._step_stream = masked_compute_stream(self.device, n)
         cur = torch.cuda.current_stream()
         st.wait_stream(cur)
-        with torch.cuda.stream(st):
-            out = fn(*args, **kw)
+        # the conv launchers size their tile rounds (split-K tail) for the CUs the masked stream can reach
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        _ops.check(_ops.lib().p2phd_set_option(b"cus", n_cu - n), "set_option(cus)")
+        try:
+            with torch.cuda.stream(st):
+                out = fn(*args, **kw)
+        finally:
+            _ops.check(_ops.lib().p2phd_set_option(b"cus", 0), "set_option(cus)")
         cur.wait_stream(st)
         return out
 

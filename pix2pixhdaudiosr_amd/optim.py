@@ -24,7 +24,7 @@ class FlatAdam(torch.optim.Optimizer):
             raise _lib.P2PHDError("FlatAdam runs on the GPU only (no CPU fallback)")
         sizes = [p.numel() for p in params]
         # 16-byte aligned slices so every parameter / gradient view can be read with float4
-        # (8 elements: the bf16 image of the weights -- see _image -- is then 16-byte aligned per parameter as well)
+        # (8 elements: a bf16 copy at the same element offsets would be 16-byte aligned per parameter as well)
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -41,22 +41,6 @@ class FlatAdam(torch.optim.Optimizer):
                 p.data = v
         self._install_grad_views()
         self.step_count = 0
-        # bf16 image of the weights, written by the update kernel at the same element offsets -- opt-in (P2PHD_ADAM_IMAGE=1).
-        # For K-major conv weights whose packed forward image is their plain cast it replaces the per-layer pack launch
-        # (_ops.ConvSpec.packed; round-2 review item 6a); the slack behind it covers the 128-row granularity of the kernels'
-        # weight descriptor.  Measured SLOWER at configs[1] B=32: 26.88 / 26.93 vs 26.49 / 26.50 ms/step over alternating
-        # runs, although 20 pack launches (0.15 ms of kernel time) leave the step: the pack in front of a layer is also what
-        # brings its 10.6 MB of weights into the Infinity Cache right before the conv's 8 XCDs each stream them; an image
-        # written by the previous step's update kernel comes from HBM.
-        self._image = None
-        import os
-        km = [p for p in params if getattr(p, "_p2phd_kmajor", False) and p.dim() == 4]
-        if km and os.environ.get("P2PHD_ADAM_IMAGE", "0") == "1":
-            slack = 128 * max(p.shape[1] * p.shape[2] * p.shape[3] for p in km)
-            self._image = torch.zeros(total + slack, dtype=torch.bfloat16, device=dev)
-            for p, o in zip(params, offs):
-                if getattr(p, "_p2phd_kmajor", False) and p.dim() == 4:
-                    p._p2phd_image = {"buf": self._image[o:], "stamp": None}
         # learning rate and step counter live on the device (p2phd_adam_step_dev): a captured step replays unchanged
         self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -174,25 +158,11 @@ class FlatAdam(torch.optim.Optimizer):
         self.sync_hyper()
         self.step_count += 1
         b1, b2 = g["betas"]
-        if self._image is None:
-            _lib.check(_lib.lib().p2phd_adam_step_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
-                                                      _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
-                                                      _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
-                                                      1.0 / self.world_size, _lib.stream_ptr()), "adam_step")
-            _ops.bump_weight_epoch()
-            return
-        _lib.check(_lib.lib().p2phd_adam_step_dev_image(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
-                                                        _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
-                                                        _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
-                                                        1.0 / self.world_size, _lib.ptr(self._image), _lib.stream_ptr()), "adam_step")
+        _lib.check(_lib.lib().p2phd_adam_step_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
+                                                  _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
+                                                  _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
+                                                  1.0 / self.world_size, _lib.stream_ptr()), "adam_step")
         _ops.bump_weight_epoch()
-        # the image now holds exactly these weights.  It stays valid as long as nothing but this kernel writes them: torch
-        # ops on the parameter move p._version; the global weight epoch is NOT part of the stamp (the other network's
-        # update bumps it too), so whoever changes weights behind torch's back must go through this optimiser
-        for p in self._params:
-            im = getattr(p, "_p2phd_image", None)
-            if im is not None:
-                im["stamp"] = (p._version, p.data_ptr())
 
     def sync_hyper(self):
         """Push param_groups[0]['lr'] to the device copy the kernel reads (only when it changed).  Called by step();

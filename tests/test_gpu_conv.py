@@ -717,93 +717,3 @@ def test_kmajor_master_weights(dtype, tol, geom):
         assert rel_err(res[1][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(res[1][2].numpy(), go[1].numpy()) < 3e-4
 
 
-def test_forward_image_written_by_the_update_kernel(monkeypatch):
-    """Opt-in P2PHD_ADAM_IMAGE=1 (round-2 review item 6a): FlatAdam's update kernel also writes the new weights as bf16 at
-    the same element offsets; for a K-major layer whose packed forward image is a plain cast that slice replaces the pack
-    launch.  Same bits as the pack kernel, taken only while nothing else wrote the parameter."""
-    import ctypes as C
-    from pix2pixhdaudiosr_amd import _ops
-    from pix2pixhdaudiosr_amd.optim import FlatAdam
-    monkeypatch.setenv("P2PHD_ADAM_IMAGE", "1")
-    cin, cout, k, N, H, W = 64, 128, 3, 2, 12, 10
-    g = torch.Generator().manual_seed(29)
-    w = torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=g) * 0.05).cuda())
-    b = torch.nn.Parameter(torch.zeros(5).cuda())                      # a second parameter in front: a non-zero, 16-byte aligned offset
-    w._p2phd_kmajor = True
-    opt = FlatAdam([b, w], lr=1e-2)
-    assert opt._image is not None and opt.param_offset(1) % 8 == 0
-    spec = _ops.ConvSpec(cin, cout, k, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
-    d = spec.desc(N, H, W, torch.bfloat16, 1)
-    assert _ops.lib().p2phd_conv_fwd_image_is_master(C.byref(d)) == 1
-    lo, hi = opt._image.data_ptr(), opt._image.data_ptr() + opt._image.numel() * 2
-    x = torch.randn(N, cin, H, W, generator=g).cuda()
-
-    def fwd():
-        return _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, x), w, None, spec), cout).detach().clone()
-
-    fwd()
-    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)          # no update yet: the pack kernel's own buffer
-    opt.zero_grad()
-    w.grad.normal_(generator=None)
-    opt.step()
-    y_img = fwd()
-    assert lo <= spec.packed(w, 0, d).data_ptr() < hi                 # the optimiser's image, no pack launch
-    w._p2phd_image["stamp"] = None                                    # same weights through the pack kernel
-    _ops.bump_weight_epoch()
-    y_pack = fwd()
-    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)
-    assert torch.equal(y_img, y_pack)
-    opt.step()                                                        # image valid again ...
-    with torch.no_grad():
-        w[:, :8].neg_()                                               # ... until torch writes the parameter
-    y_new = fwd()
-    assert not (lo <= spec.packed(w, 0, d).data_ptr() < hi)
-    assert not torch.equal(y_new, y_pack) and torch.isfinite(y_new).all()
-
-
-@pytest.mark.parametrize("case", ["down_s2", "odd_plane_k4", "convT_merged", "no_stats_act"])
-def test_persistent_gather_gemm_is_bit_identical(case):
-    """Round 3, opt-in (option gconv_persist = 1): forward-type launches of >= 2 tiles per CU on 256 x 128 tiles take the
-    persistent kernel (csrc/gconv_persist.inc: a workgroup walks its tiles and fills the next tile's ring under the current
-    epilogue).  Same arithmetic in the same order as the
-    one-tile-per-workgroup kernel: outputs and InstanceNorm means must have the same BITS (option gconv_persist 0 / 1)."""
-    import ctypes as C
-    from pix2pixhdaudiosr_amd import _ops
-    L = _ops.lib()
-    dt = torch.bfloat16
-    if case == "down_s2":           # 3x3 stride 2, 48 -> 96: 64 tiles per sample
-        cin, cout, k, stride, pad, tr, opad, N, H, W, norm, act = 48, 96, 3, 2, 1, False, 0, 8, 256, 256, True, 0
-    elif case == "odd_plane_k4":    # discriminator-like 4x4 stride 2 on an odd plane: the last tile of a sample is partial
-        cin, cout, k, stride, pad, tr, opad, N, H, W, norm, act = 64, 128, 4, 2, 2, False, 0, 16, 257, 129, True, 0
-    elif case == "convT_merged":    # transposed conv as one merged sub-pixel launch (4 classes x 32 channels = 128 columns)
-        cin, cout, k, stride, pad, tr, opad, N, H, W, norm, act = 64, 32, 3, 2, 1, True, 1, 8, 128, 128, True, 0
-    else:                           # no statistics, LeakyReLU in the epilogue, tiles straddle samples (flat M)
-        cin, cout, k, stride, pad, tr, opad, N, H, W, norm, act = 64, 128, 4, 2, 2, False, 0, 16, 257, 129, False, _ops.ACT_LRELU
-    spec = _ops.ConvSpec(cin, cout, k, stride, pad, 0, tr, opad, norm, act)
-    d = spec.desc(N, H, W, dt)
-    Ho, Wo = spec.out_size(d)
-    g = torch.Generator().manual_seed(5)
-    x = torch.randn(N, H, W, _ops.cpitch(cin), generator=g).to(dt).cuda()
-    w = (torch.randn((cin, cout, k, k) if tr else (cout, cin, k, k), generator=g) * 0.05).cuda()
-    b = torch.randn(cout, generator=g).cuda()
-    wp = spec.packed(w, 0, d)
-    ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 256), "cuda")
-    outs = []
-    try:
-        for persist in (0, 1):
-            _ops.check(L.p2phd_set_option(b"gconv_persist", persist))
-            y = torch.full((N, Ho, Wo, _ops.cpitch(cout)), float("nan"), dtype=dt, device="cuda")
-            stats = torch.zeros(N, _ops.cpitch(cout), 2, device="cuda")
-            for _ in range(2):                                             # twice: the second launch finds a warm cache
-                _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), _ops.ptr(b), act, _ops.ptr(y),
-                                            _ops.ptr(stats) if norm else None, _ops.ptr(ws), _ops.stream_ptr()))
-            torch.cuda.synchronize()
-            outs.append((y[..., :cout].float().cpu(), stats.cpu()))
-    finally:
-        _ops.check(L.p2phd_set_option(b"gconv_persist", 0))
-    assert torch.isfinite(outs[0][0]).all()
-    assert torch.equal(outs[0][0], outs[1][0])                             # every output value: same bits
-    assert torch.equal(outs[0][1][..., 0], outs[1][1][..., 0])             # means: same bits
-    # M2 (sum of squared deviations): the two kernels' compilers fuse the multiply-adds of that sum differently -- last-bit noise
-    m2a, m2b = outs[0][1][..., 1], outs[1][1][..., 1]
-    assert float(((m2a - m2b).abs() / m2a.abs().clamp_min(1e-20)).max()) < 1e-6

@@ -519,31 +519,6 @@ def test_local_enhancer_staged_backward_equals_single_backward():
     assert len(four._graph_state['graphs'][0]) == 4
 
 
-def test_weight_gradients_on_the_side_stream(golden_model, monkeypatch):
-    """P2PHD_WGRAD_STREAM=1: the weight-gradient kernels of the model's backward stages run on a second stream (their
-    operands kept alive until the join).  Same kernels on the same data: the result must agree with the single-stream
-    step to its run-to-run bound, eagerly and replayed from the captured graphs."""
-    g = golden_model
-    lr, hr = _fresh_audio(g)
-    a, b = _model(g, mask=False), _model(g, mask=False)
-    a.train_step(lr, hr)
-    monkeypatch.setenv("P2PHD_WGRAD_STREAM", "1")
-    from pix2pixhdaudiosr_amd import _ops
-    b.train_step(lr, hr)
-    assert _ops._SIDE["stream"] is not None and not _ops._SIDE["keep"] and not _ops._SIDE["on"]
-    torch.cuda.synchronize()
-    assert _grad_diff(a, b, "optimizer_G") < 1e-6 and _grad_diff(a, b, "optimizer_D") < 1e-6
-    for _ in range(4):
-        b.train_step_graphed(lr, hr)
-    assert b._graph_state['graphs'] is not None
-    monkeypatch.setenv("P2PHD_WGRAD_STREAM", "0")
-    _reset(a, g); _reset(b, g)
-    a.train_step(lr, hr)
-    b.train_step_graphed(lr, hr)                                   # the captured side-stream branches replay
-    torch.cuda.synchronize()
-    assert _grad_diff(a, b, "optimizer_G") < 1e-6 and _grad_diff(a, b, "optimizer_D") < 1e-6
-
-
 def test_niter_fix_global_and_update_fixed_params():
     """--niter_fix_global (pix2pixHD_model.py:110-131): only the outermost local enhancer's parameters are optimised; after
     update_fixed_params (:521-528) every generator parameter is, with a fresh Adam; the step captured before the switch is
