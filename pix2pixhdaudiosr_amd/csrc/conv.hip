@@ -785,7 +785,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 template <typename T, int TM>
 __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __restrict__ rows, const T* __restrict__ gat,
                                                     float* __restrict__ dwp, int Cp_r, int steps_per_split, long slab_elems,
-                                                    unsigned rows_bytes) {
+                                                    unsigned rows_bytes, int grid_nx, int grid_my, int grid_sp, int xcd_order) {
   constexpr int EPP = Elem<T>::EPP;
   constexpr int SZ = (int)sizeof(T);
   constexpr int NT = 512;
@@ -822,12 +822,44 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int j0 = blockIdx.x * TN;                           // first kk column
-  const int m0 = blockIdx.y * TM;                           // first output row
+  // 1-D launch of grid_nx (column tiles) x grid_my (row tiles) x grid_sp (pixel splits) workgroups.  Which tile a workgroup
+  // takes decides what shares an XCD's L2: workgroups are dealt round-robin over the 8 XCDs (speed only, never
+  // correctness), so physical id -> logical index L puts a CONTIGUOUS run of L on each XCD (bijective chunk remap), and L
+  // orders the tiles so that neighbours stream the same bytes at the same time: same pixel split first, then the same
+  // input-channel slice (column tiles jx = tap * slices + slice read the same pixels of the gathered tensor through
+  // different taps), then tap, then row tile (same rows-operand panel).  The 243 workgroups of a trunk layer then read
+  // each activation panel from memory about twice instead of 8 times (measured: DESIGN section 6).
+  int bx, by, bz;
+  {
+    const int W = grid_nx * grid_my * grid_sp;
+    int L = (int)blockIdx.x;
+    if (xcd_order) {
+      const int q = W >> 3, r = W & 7, xcd = L & 7, k = L >> 3;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+      by = L % grid_my;
+      const int u = L / grid_my;
+      const int slices = (d.Cp_in * SZ) % (TN * SZ) == 0 ? d.Cp_in / TN : 0;
+      if (slices > 0 && grid_nx % slices == 0 && grid_nx * TN == d.KK) {
+        const int taps = grid_nx / slices;
+        const int t = u % taps, v = u / taps;
+        bx = t * slices + v % slices;
+        bz = v / slices;
+      } else {
+        bx = u % grid_nx;
+        bz = u / grid_nx;
+      }
+    } else {
+      bx = L % grid_nx;
+      by = (L / grid_nx) % grid_my;
+      bz = L / (grid_nx * grid_my);
+    }
+  }
+  const int j0 = bx * TN;                                   // first kk column
+  const int m0 = by * TM;                                   // first output row
   const int npix = Hg * Wg;
   const long P = (long)d.N * npix;
   const int total_steps = (int)((P + BKP - 1) / BKP);
-  const int s_begin = blockIdx.z * steps_per_split;
+  const int s_begin = bz * steps_per_split;
   int s_end = s_begin + steps_per_split;
   if (s_end > total_steps) s_end = total_steps;
   const int nsteps = s_end - s_begin;                       // >= 1 by construction of the grid
@@ -1112,7 +1144,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     }
 #ifdef P2PHD_PROBE
     if (tid == 0) {
-      const unsigned wg = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) % kProbeSlots;
+      const unsigned wg = (unsigned)blockIdx.x % kProbeSlots;
       unsigned long long* r = g_probe + (size_t)wg * 8;
       r[0] += pr_wait; r[1] += pr_bar; r[2] += __builtin_readcyclecounter() - pr_t0; r[3] += (unsigned long long)nsteps;
       r[6] += 1ull;
@@ -1171,7 +1203,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     }
   }
 
-  float* slab = dwp + (size_t)blockIdx.z * slab_elems;
+  float* slab = dwp + (size_t)bz * slab_elems;
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -1967,8 +1999,9 @@ void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* 
   constexpr int lds = (TM == 256 ? 2 : 3) * (256 * (int)sizeof(T) / 128 * bkp * 128 + tilea);
   auto kern = wgrad_kernel<T, TM>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  dim3 grid((unsigned)((d.KK + 255) / 256), (unsigned)(mrows / TM), (unsigned)splits);
-  hipLaunchKernelGGL(kern, grid, dim3(512), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, slab_elems, rows_bytes);
+  const int nx = (d.KK + 255) / 256, my = mrows / TM;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nx * my * splits)), dim3(512), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, slab_elems,
+                     rows_bytes, nx, my, splits, p2phd::g_opt_wgrad_xcd);
 }
 
 // Split plan of the pixel reduction: shared by the workspace query and the launch.

@@ -80,11 +80,28 @@ bool c7_dgrad_shape(const p2phd_conv_desc* c) {
   return ok;
 }
 
+// what the packed buffer must hold for march.hip, whatever the option says at the moment (the option can change between
+// the pack and the call; the buffer layout must not)
+size_t march_shape_elems(const p2phd_conv_desc* c, int which) {
+  const int keep = g_opt_march;
+  g_opt_march = 1;
+  const size_t n = march_packed_elems(c, which);
+  g_opt_march = keep;
+  return n;
+}
+size_t generic_packed_elems(const std::vector<struct Plan>& plans);
+
 int fold_mode(const p2phd_conv_desc* c) {
   if (c->transposed || c->stride != 1) return FOLD_NONE;
   if (c->K <= 4 && c->S * c->K <= 32) return FOLD_OUT;
   if (c->C <= 4 && c->S * c->C <= 32) return FOLD_IN;
   return FOLD_NONE;
+}
+
+size_t generic_packed_elems(const std::vector<Plan>& plans) {
+  size_t n = 0;
+  for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+  return n;
 }
 
 GDesc base_desc(int N) {
@@ -287,6 +304,7 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   if (which == 0 && c7_out_shape(c)) n += c7_out_packed_elems(c);
   if (which == 1 && c7_dgrad_shape(c))                                       // + fragment-ordered copy + f32 master copy (border fix)
     return (n + c7_out_dgrad_packed_elems(c)) * elem_size(c->dtype) + (size_t)c->K * c->C * c->R * c->S * sizeof(float);
+  n += march_shape_elems(c, which);                                          // fragment-ordered copy for march.hip, behind the generic pack
   return n * elem_size(c->dtype);
 }
 
@@ -304,6 +322,13 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
       if (int rc = launch_pack_merged(p.d, c->dtype, w, dst, p.rows_pad, m.rows, m.inner, c->R, c->S, pad_eff, m.s_row, m.s_inner,
                                       (hipStream_t)stream)) return rc;
     } else if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
+  }
+  if (march_shape_elems(c, which) > 0) {
+    const int keep = g_opt_march;
+    g_opt_march = 1;
+    const int rc = march_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
+    g_opt_march = keep;
+    return rc;
   }
   if (which == 0 && c7_fast_shape(c)) {
     size_t n = 0;
@@ -380,6 +405,15 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
   }
   const void* src = x;
   float* table = static_cast<float*>(workspace);
+  if (fold == FOLD_NONE && act == P2PHD_ACT_NONE && march_kind(c, 0)) {
+    // the generator's outermost stride-2 layer: marching kernel (march.hip), weights behind the generic pack
+    const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    if (int rc = march_run(c, 0, x, wf, bias, y, stats ? table : nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st)) return rc;
+    if (stats == nullptr) return P2PHD_OK;
+    int slots = 0, slot_rows = 0;
+    march_plan(c, 0, &slots, &slot_rows, nullptr);
+    return launch_stats_merge(table, stats, c->N, slots, 1, cpitch(c->K), c->K, (long)Ho * Wo, slot_rows, st);
+  }
   if (fold == FOLD_IN && act == P2PHD_ACT_NONE && c7_in_ok(c)) {
     // dedicated 2-channel 7x7 kernel (c7.hip): halo once through LDS, weights in registers, whole-row stores
     size_t n = 0;
@@ -503,6 +537,10 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
     const float* master = reinterpret_cast<const float*>(frag + c7_out_dgrad_packed_elems(c) * elem_size(c->dtype));
     return c7_out_dgrad(c, dy, frag, master, dx, st);
   }
+  if (addend == nullptr && march_kind(c, 1)) {
+    const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    return march_run(c, 1, dy, wf, nullptr, dx, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st);
+  }
   P2PHD_REQUIRE(!(reflect || kfold) || workspace, "conv_dgrad: this layer needs p2phd_conv_dgrad_workspace_bytes of scratch");
   if (reflect && !kfold && !c->transposed && c->R == 3 && c->S == 3 && c->pad == 1 && c->stride == 1 && c->H >= 4 && c->W >= 4 &&
       !g_opt_reflect_generic) {
@@ -580,6 +618,17 @@ extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, c
   P2PHD_REQUIRE(prev_act == P2PHD_ACT_NONE || prev_act == P2PHD_ACT_RELU || prev_act == P2PHD_ACT_LRELU, "conv_dgrad_bsum: activation %d", prev_act);
   hipStream_t st = (hipStream_t)stream;
   Plan& p = plans[0];
+  if (addend == nullptr && march_kind(c, 1)) {
+    // marching kernel with the producer's sums riding on its store pass; one partial row per workgroup
+    const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    const float slope = prev_act == P2PHD_ACT_RELU ? 0.f : (prev_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+    float* part = static_cast<float*>(workspace);
+    if (int rc = march_run(c, 1, dy, wf, nullptr, dx, nullptr, prev_y, prev_stats, part, 1.f / ((float)c->H * (float)c->W), eps, slope, st)) return rc;
+    int tiles = 0;
+    march_plan(c, 1, nullptr, nullptr, &tiles);
+    const long npix = (long)c->H * c->W;
+    return launch_bsum_merge(part, bstats, c->N, npix, (int)(npix / tiles), cpitch(c->C), 0, cpitch(c->C), c->C, st);
+  }
   p.d.bs_y = prev_y;
   p.d.bs_stats = prev_stats;
   p.d.bs_out = static_cast<float*>(workspace);

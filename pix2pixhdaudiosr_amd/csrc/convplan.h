@@ -65,6 +65,7 @@ int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, in
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
+extern int g_opt_wgrad_xcd;          // 1 (default): XCD-aware tile order of the weight-gradient grid, 0: plain order (A/B)
 extern int g_opt_c7_generic;
 extern int g_opt_splitk_tail;       // 0: every tile is one workgroup, 1 (default): split-K tail where the cost model says so, 2: wherever possible (tests)
 extern int g_opt_cus;               // > 0: CUs a conv launch may count on (a CU-masked compute stream); 0 = all of the device's
@@ -86,6 +87,14 @@ bool c7_out_dgrad_ok(const p2phd_conv_desc* c);
 size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
+// march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
+extern int g_opt_march;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
+int march_kind(const p2phd_conv_desc* c, int which);
+size_t march_packed_elems(const p2phd_conv_desc* c, int which);
+int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);
+void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* slot_rows, int* bs_tiles);
+int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
+              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st);
 // thinwgrad.hip: weight gradient of the layers with <= 4 channels on one side (bf16); kind 0 = not eligible
 int thin_wgrad_kind(const p2phd_conv_desc* c);
 size_t thin_wgrad_workspace_floats(const p2phd_conv_desc* c);

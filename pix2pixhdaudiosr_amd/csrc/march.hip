@@ -1,0 +1,401 @@
+// "Marching" kernels for the stride-2 3x3 layers at the OUTER end of the generator (models/networks.py:194-195 Conv2d(ngf, 2 ngf,
+// 3, stride 2, padding 1) + InstanceNorm + ReLU and :205-206 ConvTranspose2d(2 ngf, ngf, 3, stride 2, padding 1,
+// output_padding 1), ngf = 48 at configs[1]) and for their input gradients, bf16.
+//
+// These four launches per step move 0.6 GB each for 87 GFLOP: they are HBM-bound (120 us at 5 TB/s), and as tiles of the
+// generic gather-GEMM they ran at a third of that (profiles/r03_outer_layer_probe.log: 24 k of a tile's 36 k cycles are gather
+// table, ring fill, statistics and store loop, with one workgroup per CU and nothing to overlap them with).  Here:
+//   * a workgroup (12 waves) owns a COLUMN STRIP of one sample and marches down it, one output row per step; the input rows
+//     it needs live in a 5-row LDS ring, so every input byte is fetched ONCE (two new rows per step, coalesced 16-byte
+//     loads issued a whole step before they are written to LDS), and the address arithmetic of a step is a handful of adds
+//     -- no gather table;
+//   * the packed weights never touch LDS: every wave keeps the B fragments of ITS 16 output channels for all 9 taps in
+//     registers for the life of the workgroup (60 VGPRs at 48 input channels), A fragments come from the ring with
+//     conflict-free ds_read_b128 (pixel pitch padded by 16 bytes), v_mfma_f32_16x16x32_bf16;
+//   * the output tile of a step is staged in LDS and leaves one step later as whole 16-byte pieces of contiguous NHWC rows
+//     (one piece per thread), so ONE barrier per step orders ring writes, staging and stores;
+//   * InstanceNorm partials: every lane keeps running (count, mean, M2) of its channel over the whole march (Chan's
+//     update per step), merged across the four lanes of a channel at the end: one table slot per wave and launch, no atomics;
+//   * input-gradient launches can carry the producer's InstanceNorm-backward sums (the fused form of conv.hip's store
+//     loop): the storing thread owns one 8-channel column for the whole march, so the sums stay in registers.
+#include "convplan.h"
+
+namespace {
+
+using namespace p2phd;
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+constexpr int kThreads = 768, kWaves = 12;
+constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
+  const float n = na + nb;
+  const float d = mb - ma, f = n > 0.f ? nb / n : 0.f;
+  ma += d * f;
+  qa += qb + d * d * na * f;
+  na = n;
+}
+
+struct MarchArgs {
+  const bf16_t* in;       // [N, Hin, Win, CI]
+  const bf16_t* wf;       // fragment-ordered weights (march_pack_kernel)
+  const float* bias;      // [CO] or nullptr
+  bf16_t* out;            // [N, Ho, Wo, CO]
+  float* table;           // InstanceNorm partials [N][slots][CO][2] or nullptr
+  int N, Hin, Win, Ho, Wo;
+  int strips, nseg, seg_rows, slots;
+  unsigned in_bytes;
+  // fused first pass of the PRODUCER's InstanceNorm backward (input-gradient launches; conv.hip GDesc::bs_*)
+  const bf16_t* bs_y;     // pre-normalisation output of the producer, shape of `out`
+  const float* bs_stats;  // [N][CO][2] (mean, M2)
+  float* bs_out;          // [N][strips * nseg][CO][2] or nullptr
+  float bs_inv_hw, bs_eps, bs_slope;
+};
+
+// geometry of one (CI, CO, WS) instance of the stride-2 gather ("S") kernel
+template <int CI, int CO, int WS>
+struct SGeom {
+  static constexpr int CQ = CI / 8;                         // 16-byte chunks per input pixel
+  static constexpr int KSR = (3 * CQ + 3) / 4;              // k-steps (32 channels-of-taps) per tap ROW; pad chunks carry zero weights
+  static constexpr int KS = 3 * KSR;
+  static constexpr int NWN = CO / 16, NWM = kWaves / NWN;   // waves over output channels / over the strip's pixels
+  static constexpr int MBW = WS / 16 / NWM;                 // 16-pixel blocks per wave and step
+  static constexpr int RW = 2 * WS + 1;                     // input pixels per ring row
+  static constexpr int PXB = CI * 2 + 16;                   // ring pixel pitch (bytes): stride-2 fragment reads hit 16 distinct 16-byte slots
+  static constexpr int ROWB = RW * PXB;
+  static constexpr int RING = 5 * ROWB;
+  static constexpr int SPXB = CO * 2 + 16;                  // staging pixel pitch
+  static constexpr int STAGEB = WS * SPXB;
+  static constexpr int LDS = RING + 2 * STAGEB;
+  static constexpr int NCH = 2 * RW * CQ;                   // chunks of the two new rows of a step
+  static constexpr int LPT = (NCH + kThreads - 1) / kThreads;
+  static_assert(CI % 16 == 0 && CO % 16 == 0 && kWaves % NWN == 0 && (WS / 16) % NWM == 0, "march: wave grid");
+  static_assert(WS * (CO / 8) == kThreads, "march: one staged piece per thread");
+  static_assert(ROWB % 16 == 0 && (3 * CQ) % 4 != 1 && (3 * CQ) % 4 != 3, "march: pad chunks come in pairs");
+};
+
+// wf[((wn * KS + i) * 64 + lane) * 8 + e] = w[o = 16 wn + (lane & 15)][ci = 8 q + e][r][s3] for k-step i = r * KSR + ii, chunk
+// c = 4 ii + (lane >> 4) of tap row r (s3 = c / CQ, q = c % CQ), zero for the pad chunks c >= 3 CQ.
+// Master tensor: element (o, ci, r, s) at o * s_o + ci * s_i + r * 3 + s -- Conv2d weight [K][C][3][3] (o = K) for the forward,
+// ConvTranspose2d weight [Cin][Cout][3][3] (o = Cin) for its input gradient: the same index pattern.
+template <int CI, int CO>
+__global__ void march_s_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, long s_o, long s_i) {
+  constexpr int CQ = CI / 8, KSR = (3 * CQ + 3) / 4, KS = 3 * KSR;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (CO / 16) * KS * 64) return;
+  const int lane = idx & 63, i = (idx >> 6) % KS, wn = (idx >> 6) / KS;
+  const int o = 16 * wn + (lane & 15), kq = lane >> 4;
+  const int r = i / KSR, c = 4 * (i % KSR) + kq;
+  bf16_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    float f = 0.f;
+    if (c < 3 * CQ) {
+      const int s3 = c / CQ, q = c % CQ;
+      f = w[(long)o * s_o + (long)(8 * q + e) * s_i + r * 3 + s3];
+    }
+    v[e] = (bf16_t)f;
+  }
+  *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
+}
+
+// out[n, ho, wo, k] = sum_{r,s,c} in[n, 2 ho + r - 1, 2 wo + s - 1, c] * W[k][c][r][s]   (zeros outside the image)
+template <int CI, int CO, int WS>
+__global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
+  typedef SGeom<CI, CO, WS> G;
+  constexpr int CQ = G::CQ, KSR = G::KSR, KS = G::KS, NWN = G::NWN, MBW = G::MBW, RW = G::RW, PXB = G::PXB, ROWB = G::ROWB;
+  constexpr int SPXB = G::SPXB, STAGEB = G::STAGEB, LPT = G::LPT, NCH = G::NCH;
+  extern __shared__ float4 smem_raw[];
+  char* smem = reinterpret_cast<char*>(smem_raw);
+  char* stage = smem + G::RING;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave % NWN, wm = wave / NWN;
+  const int n16 = lane & 15, kq = lane >> 4;
+
+  // workgroup -> (sample, strip, segment)
+  int wg = (int)blockIdx.x;
+  const int seg = wg % a.nseg; wg /= a.nseg;
+  const int strip = wg % a.strips;
+  const int n = wg / a.strips;
+  const int wo0 = strip * WS, h_first = seg * a.seg_rows;
+  const int Hin = a.Hin, Win = a.Win;
+
+  // B fragments of this wave's 16 output channels: resident for the whole march
+  bf16x8 bfrag[KS];
+#pragma unroll
+  for (int i = 0; i < KS; ++i)
+    bfrag[i] = *reinterpret_cast<const bf16x8*>(a.wf + ((size_t)(wn * KS + i) * 64 + lane) * 8);
+  const float bias_n = a.bias != nullptr ? a.bias[16 * wn + n16] : 0.f;
+
+  // A-fragment byte offsets inside a ring row, per k-step of a tap row: lane (m = n16, kq) reads chunk c = 4 ii + kq of pixel
+  // 2 m + s3 (pad chunks re-read the chunk two to the left: finite data under zero weights)
+  unsigned aoff[KSR];
+#pragma unroll
+  for (int ii = 0; ii < KSR; ++ii) {
+    int c = 4 * ii + kq;
+    if (c >= 3 * CQ) c -= 2;
+    const int s3 = c / CQ, q = c - s3 * CQ;
+    aoff[ii] = (unsigned)((2 * n16 + s3) * PXB + q * 16 + wm * MBW * 32 * PXB);
+  }
+
+  // the two new input rows of a step, as 16-byte chunks: chunk j = tid + 768 u -> (row rr, pixel x, channel chunk q)
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+  unsigned colB[LPT], lw[LPT];
+  int rr_of[LPT];
+#pragma unroll
+  for (int u = 0; u < LPT; ++u) {
+    const int j = tid + kThreads * u;
+    const int rr = j / (RW * CQ), rem = j - rr * (RW * CQ);
+    const int x = rem / CQ, q = rem - x * CQ;
+    const int wi = 2 * wo0 - 1 + x;
+    const bool ok = j < NCH && wi >= 0 && wi < Win;
+    rr_of[u] = rr;
+    colB[u] = ok ? (unsigned)((wi * CI + 8 * q) * 2) : kOOB;
+    lw[u] = (unsigned)(min(x, RW - 1) * PXB + q * 16);
+  }
+  const unsigned sampleB = (unsigned)((size_t)n * Hin * Win * CI * 2);
+  const unsigned rowpitchB = (unsigned)(Win * CI * 2);
+  u32x4 ld[LPT];
+  // loads of abs rows (a_first, a_first + 1) of this segment: input row hi = 2 h_first - 1 + a
+  auto issue_rows = [&](int a_first) {
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int hi = 2 * h_first - 1 + a_first + rr_of[u];
+      const bool ok = hi >= 0 && hi < Hin && colB[u] != kOOB;
+      const unsigned off = ok ? sampleB + (unsigned)hi * rowpitchB + colB[u] : kOOB;
+      ld[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0);
+    }
+  };
+  auto write_rows = [&](int a_first) {
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int slot = (a_first + rr_of[u] + 5) % 5;
+      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = ld[u];
+    }
+  };
+
+  // prologue: abs rows -1 (unused), 0, then 1, 2
+  issue_rows(-1);
+  write_rows(-1);
+  issue_rows(1);
+  write_rows(1);
+  __syncthreads();
+
+  f32x4 acc[MBW];
+  float st_n = 0.f, st_mean = 0.f, st_m2 = 0.f;               // running statistics of this lane's channel
+  // fused InstanceNorm-backward sums: this thread stores piece column `pcol` of every row
+  constexpr int CPR = CO / 8;
+  const int ppx = tid / CPR, pcol = tid - ppx * CPR;
+  float bs_a1[8], bs_a2[8], bs_mean[8], bs_rstd[8];
+  const bool bsum = a.bs_out != nullptr;
+  if (bsum) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float2 ms = *reinterpret_cast<const float2*>(a.bs_stats + 2 * ((size_t)n * CO + 8 * pcol + e));
+      bs_mean[e] = ms.x;
+      bs_rstd[e] = rsqrtf(fmaxf(ms.y * a.bs_inv_hw, 0.f) + a.bs_eps);
+      bs_a1[e] = bs_a2[e] = 0.f;
+    }
+  }
+  const size_t out_sample = (size_t)n * a.Ho * a.Wo * CO;
+
+  auto store_tile = [&](int s_prev, u32x4 yv) {
+    // tile of step s_prev (staged one step ago): one 16-byte piece per thread, contiguous NHWC rows
+    const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (s_prev & 1) * STAGEB + ppx * SPXB + pcol * 16);
+    const size_t o = out_sample + ((size_t)(h_first + s_prev) * a.Wo + wo0 + ppx) * CO + 8 * pcol;
+    *reinterpret_cast<u32x4*>(a.out + o) = v;
+    if (bsum) {
+      const bf16_t* gg = reinterpret_cast<const bf16_t*>(&v);      // the ROUNDED gradient: what the apply pass will read
+      const bf16_t* yy = reinterpret_cast<const bf16_t*>(&yv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float yh = ((float)yy[e] - bs_mean[e]) * bs_rstd[e];
+        const float gp = (float)gg[e] * (yh > 0.f ? 1.f : a.bs_slope);
+        bs_a1[e] += gp; bs_a2[e] += gp * yh;
+      }
+    }
+  };
+
+  const int nsteps = a.seg_rows;
+  int a0 = 0;                                                   // (2 s) % 5
+  for (int s = 0; s < nsteps; ++s) {
+    // (the producer's pre-normalisation piece of the row stored in this step: requested BEFORE the row loads, so that waiting
+    // for it leaves those in flight -- vmcnt retires in issue order)
+    u32x4 yv = {0u, 0u, 0u, 0u};
+    if (bsum && s > 0)
+      yv = *reinterpret_cast<const u32x4*>(a.bs_y + out_sample + ((size_t)(h_first + s - 1) * a.Wo + wo0 + ppx) * CO + 8 * pcol);
+    if (s + 1 < nsteps) issue_rows(2 * s + 3);
+
+    // ---- this step's output row: 16 channels x MBW pixel blocks per wave, K = 9 taps x CI ----
+#pragma unroll
+    for (int b = 0; b < MBW; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int slot = a0 + r;
+      slot = slot >= 5 ? slot - 5 : slot;
+      const char* rowp = smem + slot * ROWB;
+#pragma unroll
+      for (int ii = 0; ii < KSR; ++ii) {
+#pragma unroll
+        for (int b = 0; b < MBW; ++b) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(rowp + aoff[ii] + b * 32 * PXB);
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[r * KSR + ii], acc[b], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- bias, statistics, staging (lane = channel n16, registers = pixels 4 kq + e of block b) ----
+    {
+      float v[MBW][4];
+      float sum = 0.f;
+#pragma unroll
+      for (int b = 0; b < MBW; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[b][e] = acc[b][e] + bias_n; sum += v[b][e]; }
+      if (a.table != nullptr) {
+        const float mb = sum * (1.f / (4 * MBW));
+        float q = 0.f;
+#pragma unroll
+        for (int b = 0; b < MBW; ++b)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float dlt = v[b][e] - mb; q += dlt * dlt; }
+        chan_merge(st_n, st_mean, st_m2, (float)(4 * MBW), mb, q);
+      }
+      char* sp = stage + (s & 1) * STAGEB + (16 * wn + n16) * 2;
+#pragma unroll
+      for (int b = 0; b < MBW; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<bf16_t*>(sp + (16 * (wm * MBW + b) + 4 * kq + e) * SPXB) = (bf16_t)v[b][e];
+    }
+
+    if (s > 0) store_tile(s - 1, yv);
+    if (s + 1 < nsteps) write_rows(2 * s + 3);
+    __syncthreads();
+    a0 += 2;
+    a0 = a0 >= 5 ? a0 - 5 : a0;
+  }
+  {
+    u32x4 yv = {0u, 0u, 0u, 0u};
+    if (bsum)
+      yv = *reinterpret_cast<const u32x4*>(a.bs_y + out_sample + ((size_t)(h_first + nsteps - 1) * a.Wo + wo0 + ppx) * CO + 8 * pcol);
+    store_tile(nsteps - 1, yv);
+  }
+
+  if (a.table != nullptr) {
+    // the four lanes (kq) of a channel -> one (sum, M2) partial per wave: slot = ((strip * nseg + seg) * NWM + wm)
+    float nn = st_n, mm = st_mean, qq = st_m2;
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float n2 = __shfl_xor(nn, o), m2 = __shfl_xor(mm, o), q2 = __shfl_xor(qq, o);
+      chan_merge(nn, mm, qq, n2, m2, q2);
+    }
+    if (kq == 0) {
+      const int slot = (strip * a.nseg + seg) * G::NWM + wm;
+      float* sp = a.table + 2 * (((size_t)n * a.slots + slot) * CO + 16 * wn + n16);
+      sp[0] = mm * nn;
+      sp[1] = qq;
+    }
+  }
+  if (bsum) {
+    // fold the sums of the WS threads of a piece column in a fixed order (no atomics): [tid][16] floats through the ring
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs_a1[e]; red[tid * 16 + 8 + e] = bs_a2[e]; }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int ch = tid >> 1, which = tid & 1, pc = ch >> 3, e = ch & 7;
+      float sum = 0.f;
+      for (int p = 0; p < WS; ++p) sum += red[(p * CPR + pc) * 16 + which * 8 + e];
+      a.bs_out[(((size_t)n * (a.strips * a.nseg) + strip * a.nseg + seg) * CO + ch) * 2 + which] = sum;
+    }
+  }
+}
+
+// segments per strip: enough workgroups for two rounds of the CUs when the plane allows, rows per segment >= 4
+int pick_segments(int N, int strips, int Ho) {
+  const int cus = g_opt_cus > 0 ? g_opt_cus : device_cus();
+  int best = 1;
+  for (int nseg = 1; nseg <= Ho; ++nseg) {
+    if (Ho % nseg != 0 || Ho / nseg < 4) continue;
+    best = nseg;
+    if ((long)N * strips * nseg >= cus) break;
+  }
+  return best;
+}
+
+}  // namespace
+
+namespace p2phd {
+
+// kind of marching kernel a layer's launch takes (0 = none).  which: 0 = forward, 1 = input gradient.
+//   1 = "S" 48 -> 96: Conv2d(48, 96, 3, s2, p1) forward, or the input gradient of ConvTranspose2d(96, 48, 3, s2, p1, op1)
+int march_kind(const p2phd_conv_desc* c, int which) {
+  if (g_opt_march == 0 || c->dtype != P2PHD_BF16 || c->R != 3 || c->S != 3 || c->stride != 2 || c->pad != 1 || c->pad_mode != 0) return 0;
+  if (which == 0 && !c->transposed && c->C == 48 && c->K == 96 && c->H % 2 == 0 && c->W % 128 == 0 && c->H >= 8) return 1;
+  if (which == 1 && c->transposed && c->opad == 1 && c->C == 96 && c->K == 48 && c->W % 64 == 0 && c->H >= 4) return 1;
+  return 0;
+}
+
+size_t march_packed_elems(const p2phd_conv_desc* c, int which) {
+  const int kind = march_kind(c, which);
+  if (kind == 1) return (size_t)(96 / 16) * SGeom<48, 96, 64>::KS * 64 * 8;
+  return 0;
+}
+
+int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st) {
+  const int kind = march_kind(c, which);
+  if (kind == 1) {
+    // forward: Conv2d weight [K=96][C=48][3][3]; input gradient of ConvTranspose2d: weight [Cin=96][Cout=48][3][3]
+    const int total = (96 / 16) * SGeom<48, 96, 64>::KS * 64;
+    hipLaunchKernelGGL((march_s_pack_kernel<48, 96>), dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, (long)48 * 9, (long)9);
+    return check_launch("march_pack");
+  }
+  set_error("march_pack: layer has no marching kernel");
+  return P2PHD_EINVAL;
+}
+
+// geometry of the launch `march_run` will make: statistics slots per sample and rows per slot; fused-sums tiles per sample
+void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* slot_rows, int* bs_tiles) {
+  // output plane of the S kernel: forward -> (H/2, W/2); input gradient of the transposed layer -> its input (H, W)
+  const int Ho = which == 0 ? c->H / 2 : c->H, Wo = which == 0 ? c->W / 2 : c->W;
+  const int strips = Wo / 64;
+  const int nseg = pick_segments(c->N, strips, Ho);
+  if (slots) *slots = strips * nseg * SGeom<48, 96, 64>::NWM;
+  if (slot_rows) *slot_rows = (Ho / nseg) * (64 / SGeom<48, 96, 64>::NWM);
+  if (bs_tiles) *bs_tiles = strips * nseg;
+}
+
+int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
+              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st) {
+  const int kind = march_kind(c, which);
+  P2PHD_REQUIRE(kind == 1, "march_run: layer has no marching kernel");
+  typedef SGeom<48, 96, 64> G;
+  MarchArgs a{};
+  a.in = (const bf16_t*)in; a.wf = (const bf16_t*)wf; a.bias = bias; a.out = (bf16_t*)out; a.table = table;
+  a.N = c->N;
+  if (which == 0) { a.Hin = c->H; a.Win = c->W; a.Ho = c->H / 2; a.Wo = c->W / 2; }
+  else { a.Hin = 2 * c->H; a.Win = 2 * c->W; a.Ho = c->H; a.Wo = c->W; }     // gathers dy [N, 2H, 2W, 48], writes dx [N, H, W, 96]
+  a.strips = a.Wo / 64;
+  a.nseg = pick_segments(a.N, a.strips, a.Ho);
+  a.seg_rows = a.Ho / a.nseg;
+  a.slots = a.strips * a.nseg * G::NWM;
+  const size_t ib = (size_t)a.N * a.Hin * a.Win * 48 * 2;
+  P2PHD_REQUIRE(ib < 0xFFFFFFF0ull, "march: tensor larger than 4 GiB");
+  a.in_bytes = (unsigned)ib;
+  a.bs_y = (const bf16_t*)bs_y; a.bs_stats = bs_stats; a.bs_out = bs_out;
+  a.bs_inv_hw = bs_inv_hw; a.bs_eps = bs_eps; a.bs_slope = bs_slope;
+  auto kern = march_s_kernel<48, 96, 64>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.strips * a.nseg)), dim3(kThreads), G::LDS, st, a);
+  return check_launch("march_s");
+}
+
+}  // namespace p2phd
