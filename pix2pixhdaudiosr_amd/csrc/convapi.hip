@@ -410,9 +410,10 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
     const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
     if (int rc = march_run(c, 0, x, wf, bias, y, stats ? table : nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st)) return rc;
     if (stats == nullptr) return P2PHD_OK;
-    int slots = 0, slot_rows = 0;
-    march_plan(c, 0, &slots, &slot_rows, nullptr);
-    return launch_stats_merge(table, stats, c->N, slots, 1, cpitch(c->K), c->K, (long)Ho * Wo, slot_rows, st);
+    int slots = 0, ncls = 1, slot_rows = 0;
+    long npix_cls = 0;
+    march_plan(c, 0, &slots, &ncls, &slot_rows, &npix_cls, nullptr);
+    return launch_stats_merge(table, stats, c->N, slots, ncls, cpitch(c->K), c->K, npix_cls, slot_rows, st);
   }
   if (fold == FOLD_IN && act == P2PHD_ACT_NONE && c7_in_ok(c)) {
     // dedicated 2-channel 7x7 kernel (c7.hip): halo once through LDS, weights in registers, whole-row stores
@@ -625,7 +626,7 @@ extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, c
     float* part = static_cast<float*>(workspace);
     if (int rc = march_run(c, 1, dy, wf, nullptr, dx, nullptr, prev_y, prev_stats, part, 1.f / ((float)c->H * (float)c->W), eps, slope, st)) return rc;
     int tiles = 0;
-    march_plan(c, 1, nullptr, nullptr, &tiles);
+    march_plan(c, 1, nullptr, nullptr, nullptr, nullptr, &tiles);
     const long npix = (long)c->H * c->W;
     return launch_bsum_merge(part, bstats, c->N, npix, (int)(npix / tiles), cpitch(c->C), 0, cpitch(c->C), c->C, st);
   }

@@ -92,7 +92,7 @@ extern int g_opt_march;            // 1 (default): eligible layers take the marc
 int march_kind(const p2phd_conv_desc* c, int which);
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);
-void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* slot_rows, int* bs_tiles);
+void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* ncls, int* slot_rows, long* npix_cls, int* bs_tiles);
 int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
               const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st);
 // thinwgrad.hip: weight gradient of the layers with <= 4 channels on one side (bf16); kind 0 = not eligible

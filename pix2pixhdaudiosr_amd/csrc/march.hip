@@ -104,7 +104,7 @@ __global__ void march_s_pack_kernel(const float* __restrict__ w, bf16_t* __restr
 }
 
 // out[n, ho, wo, k] = sum_{r,s,c} in[n, 2 ho + r - 1, 2 wo + s - 1, c] * W[k][c][r][s]   (zeros outside the image)
-template <int CI, int CO, int WS>
+template <int CI, int CO, int WS, bool BSUM>
 __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
   typedef SGeom<CI, CO, WS> G;
   constexpr int CQ = G::CQ, KSR = G::KSR, KS = G::KS, NWN = G::NWN, MBW = G::MBW, RW = G::RW, PXB = G::PXB, ROWB = G::ROWB;
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
   constexpr int CPR = CO / 8;
   const int ppx = tid / CPR, pcol = tid - ppx * CPR;
   float bs_a1[8], bs_a2[8], bs_mean[8], bs_rstd[8];
-  const bool bsum = a.bs_out != nullptr;
+  constexpr bool bsum = BSUM;                                   // (its own instance: the sums cost 36 registers)
   if (bsum) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -259,13 +259,18 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[b][e] = acc[b][e] + bias_n; sum += v[b][e]; }
       if (a.table != nullptr) {
+        // Chan's update with equal batches: after s steps the lane holds n_a = 4 MBW s values, the batch has n_b = 4 MBW, so
+        // n_b / n = 1 / (s + 1) and n_a n_b / n = 4 MBW s / (s + 1): one reciprocal per step, none per lane
         const float mb = sum * (1.f / (4 * MBW));
         float q = 0.f;
 #pragma unroll
         for (int b = 0; b < MBW; ++b)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float dlt = v[b][e] - mb; q += dlt * dlt; }
-        chan_merge(st_n, st_mean, st_m2, (float)(4 * MBW), mb, q);
+        const float f = 1.f / (float)(s + 1), d = mb - st_mean;
+        st_mean += d * f;
+        st_m2 += q + d * d * ((float)(4 * MBW * s) * f);
+        st_n = (float)(4 * MBW * (s + 1));
       }
       char* sp = stage + (s & 1) * STAGEB + (16 * wn + n16) * 2;
 #pragma unroll
@@ -319,6 +324,290 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// "U" kernel: the transposed form -- out[n, 2 a + pi, 2 b + pj, k] = sum over the taps (r, s) of parity class (pi, pj) of
+// in[n, a + dr, b + dc, c] * W[c][k][r][s]: ConvTranspose2d(CI, CO, 3, stride 2, padding 1, output_padding 1) forward, and the
+// input gradient of Conv2d(CO, CI, 3, stride 2, padding 1).  Class (0,0) has one tap, (0,1) and (1,0) two, (1,1) four:
+//   pi = 0: (dr 0, r 1);   pi = 1: (dr 0, r 2), (dr 1, r 0);   the same for (pj, dc, s).
+// A workgroup marches down a strip of WS INPUT pixels: step a reads input rows a, a + 1 (3-row ring, one new row per step) and
+// writes output rows 2 a, 2 a + 1 of 2 WS pixels.  12 waves = 3 channel blocks x 2 pixel groups x 2 ROLES: role A computes
+// class (1,1) (4 taps), role B the other three classes (5 taps, the (0,0)-neighbour fragments shared by all three) -- 12 / 15
+// B fragments resident per wave, no zero blocks multiplied.
+// ------------------------------------------------------------------------------------------------------------------------
+template <int CI, int CO, int WS>
+struct UGeom {
+  static constexpr int CQ = CI / 8;
+  static constexpr int KN = CQ / 4;                         // k-steps per neighbour pixel
+  static constexpr int NB = CO / 16;                        // channel blocks
+  static constexpr int NWM = kWaves / (2 * NB);             // pixel groups
+  static constexpr int MBW = WS / 16 / NWM;
+  static constexpr int RW = WS + 1;
+  static constexpr int PXB = CI * 2 + 32;                   // pixel pitch = 16 * 14 (mod 256): the 16-lane groups of ds_read_b128 hit 16 slots
+  static constexpr int ROWB = RW * PXB;
+  static constexpr int RING = 3 * ROWB;
+  static constexpr int SPXB = CO * 2 + 16;
+  static constexpr int STAGEB = 2 * (2 * WS) * SPXB;        // two output rows of 2 WS pixels
+  static constexpr int TABB = CO * 2 * 4;                   // (mean, rstd) of the fused backward sums
+  static constexpr int LDS = RING + 2 * STAGEB + TABB;
+  static constexpr int NCH = RW * CQ;
+  static constexpr int LPT = (NCH + kThreads - 1) / kThreads;
+  static constexpr int FA = 4 * KN, FB = 5 * KN;            // resident B fragments of a role-A / role-B wave
+  static_assert(CQ % 4 == 0 && kWaves % (2 * NB) == 0 && (WS / 16) % NWM == 0, "march(U): wave grid");
+  static_assert(2 * WS * (CO / 8) == kThreads, "march(U): one staged piece per thread and output row");
+  static_assert(ROWB % 16 == 0 && RING % 16 == 0 && STAGEB % 16 == 0, "march(U): alignment");
+};
+
+// tap of class parity p reached through neighbour offset d (0 / 1): kernel coordinate, or -1
+__host__ __device__ constexpr int u_tap(int p, int d) { return p == 0 ? (d == 0 ? 1 : -1) : (d == 0 ? 2 : 0); }
+
+// wf: role A, block nb: fragments [(dr, dc) in 00 01 10 11][kk]; role B, block nb: class 00: [00][kk]; class 01: [00][kk], [01][kk];
+// class 10: [00][kk], [10][kk].  Fragment = 64 lanes x 8 bf16: W[ci = 32 kk + 8 (lane >> 4) + e][o = 16 nb + (lane & 15)][r][s].
+// Master tensor element (ci, o, r, s) at ci * s_i + o * s_o + 3 r + s.
+template <int CI, int CO>
+__global__ void march_u_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ wf, long s_i, long s_o) {
+  constexpr int KN = CI / 32, NB = CO / 16, FA = 4 * KN, FB = 5 * KN;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NB * (FA + FB) * 64) return;
+  const int lane = idx & 63, f = (idx >> 6) % (FA + FB), nb = (idx >> 6) / (FA + FB);
+  int pi, pj, dr, dc, kk;
+  if (f < FA) { pi = pj = 1; dr = (f / KN) >> 1; dc = (f / KN) & 1; kk = f % KN; }
+  else {
+    const int g = (f - FA) / KN;                            // 0: cls00/d00  1: cls01/d00  2: cls01/d01  3: cls10/d00  4: cls10/d10
+    kk = (f - FA) % KN;
+    pi = g >= 3 ? 1 : 0; pj = (g == 1 || g == 2) ? 1 : 0;
+    dr = g == 4 ? 1 : 0; dc = g == 2 ? 1 : 0;
+  }
+  const int r = u_tap(pi, dr), s3 = u_tap(pj, dc);
+  const int o = 16 * nb + (lane & 15), kq = lane >> 4;
+  bf16_t v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)w[(long)(32 * kk + 8 * kq + e) * s_i + (long)o * s_o + 3 * r + s3];
+  *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
+}
+
+template <int CI, int CO, int WS, bool BSUM>
+__global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
+  typedef UGeom<CI, CO, WS> G;
+  constexpr int CQ = G::CQ, KN = G::KN, NB = G::NB, MBW = G::MBW, RW = G::RW, PXB = G::PXB, ROWB = G::ROWB;
+  constexpr int SPXB = G::SPXB, STAGEB = G::STAGEB, LPT = G::LPT, NCH = G::NCH, FA = G::FA, FB = G::FB;
+  extern __shared__ float4 smem_raw[];
+  char* smem = reinterpret_cast<char*>(smem_raw);
+  char* stage = smem + G::RING;
+  float* bs_tab = reinterpret_cast<float*>(smem + G::RING + 2 * STAGEB);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nb = wave % NB, role = (wave / NB) & 1, wm = wave / (2 * NB);
+  const int n16 = lane & 15, kq = lane >> 4;
+
+  int wg = (int)blockIdx.x;
+  const int seg = wg % a.nseg; wg /= a.nseg;
+  const int strip = wg % a.strips;
+  const int n = wg / a.strips;
+  const int wi0 = strip * WS, i_first = seg * a.seg_rows;
+  const int Hin = a.Hin, Win = a.Win, Hout = a.Ho, Wout = a.Wo;
+
+  // resident B fragments (role A: FA, role B: FB; the array is sized for the larger)
+  bf16x8 bfrag[FB];
+  {
+    const bf16_t* wfw = a.wf + ((size_t)nb * (FA + FB) + (role ? FA : 0)) * 64 * 8;
+#pragma unroll
+    for (int f = 0; f < FB; ++f)
+      bfrag[f] = (role || f < FA) ? *reinterpret_cast<const bf16x8*>(wfw + ((size_t)f * 64 + lane) * 8) : bf16x8{};
+  }
+  const float bias_n = a.bias != nullptr ? a.bias[16 * nb + n16] : 0.f;
+  const unsigned abase = (unsigned)((16 * wm * MBW + n16) * PXB + kq * 16);
+
+  // the new input row of a step as 16-byte chunks
+  const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
+  unsigned colB[LPT], lw[LPT];
+#pragma unroll
+  for (int u = 0; u < LPT; ++u) {
+    const int j = tid + kThreads * u;
+    const int x = j / CQ, q = j - x * CQ;
+    const int wi = wi0 + x;
+    colB[u] = (j < NCH && wi < Win) ? (unsigned)((wi * CI + 8 * q) * 2) : kOOB;
+    lw[u] = (unsigned)(min(x, RW - 1) * PXB + q * 16);
+  }
+  const unsigned sampleB = (unsigned)((size_t)n * Hin * Win * CI * 2);
+  const unsigned rowpitchB = (unsigned)(Win * CI * 2);
+  u32x4 ld[LPT];
+  auto issue_row = [&](int arel) {                                // input row i_first + arel (zeros past the image)
+    const int hi = i_first + arel;
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const unsigned off = (hi < Hin && colB[u] != kOOB) ? sampleB + (unsigned)hi * rowpitchB + colB[u] : kOOB;
+      ld[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0);
+    }
+  };
+  auto write_row = [&](int arel) {
+    const int slot = arel % 3;
+#pragma unroll
+    for (int u = 0; u < LPT; ++u)
+      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = ld[u];
+  };
+
+  constexpr int CPR = CO / 8;
+  const int ppx = tid / CPR, pcol = tid - ppx * CPR;            // this thread's piece of BOTH output rows of a step
+  constexpr bool bsum = BSUM;
+  float bs_a1[8], bs_a2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bs_a1[e] = bs_a2[e] = 0.f;
+  if (bsum && tid < CO) {
+    const float2 ms = *reinterpret_cast<const float2*>(a.bs_stats + 2 * ((size_t)n * CO + tid));
+    bs_tab[2 * tid] = ms.x;
+    bs_tab[2 * tid + 1] = rsqrtf(fmaxf(ms.y * a.bs_inv_hw, 0.f) + a.bs_eps);
+  }
+  issue_row(0);
+  write_row(0);
+  issue_row(1);
+  write_row(1);
+  __syncthreads();
+
+  const size_t out_sample = (size_t)n * Hout * Wout * CO;
+  auto piece_off = [&](int s_step, int rho) -> size_t {
+    return out_sample + ((size_t)(2 * (i_first + s_step) + rho) * Wout + 2 * wi0 + ppx) * CO + 8 * pcol;
+  };
+  auto store_tile = [&](int s_prev, u32x4 y0, u32x4 y1) {
+#pragma unroll
+    for (int rho = 0; rho < 2; ++rho) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(stage + (s_prev & 1) * STAGEB + (rho * 2 * WS + ppx) * SPXB + pcol * 16);
+      *reinterpret_cast<u32x4*>(a.out + piece_off(s_prev, rho)) = v;
+      if (bsum) {
+        const u32x4 yv = rho ? y1 : y0;
+        const bf16_t* gg = reinterpret_cast<const bf16_t*>(&v);
+        const bf16_t* yy = reinterpret_cast<const bf16_t*>(&yv);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(bs_tab + 16 * pcol), t1 = *reinterpret_cast<const f32x4*>(bs_tab + 16 * pcol + 4);
+        const f32x4 t2 = *reinterpret_cast<const f32x4*>(bs_tab + 16 * pcol + 8), t3 = *reinterpret_cast<const f32x4*>(bs_tab + 16 * pcol + 12);
+        const float mr[16] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3], t2[0], t2[1], t2[2], t2[3], t3[0], t3[1], t3[2], t3[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float yh = ((float)yy[e] - mr[2 * e]) * mr[2 * e + 1];
+          const float gp = (float)gg[e] * (yh > 0.f ? 1.f : a.bs_slope);
+          bs_a1[e] += gp; bs_a2[e] += gp * yh;
+        }
+      }
+    }
+  };
+
+  // running statistics per class this wave computes (role A: class 11 in slot 0; role B: classes 00, 01, 10)
+  float st_n[3] = {0.f, 0.f, 0.f}, st_mean[3] = {0.f, 0.f, 0.f}, st_m2[3] = {0.f, 0.f, 0.f};
+  const int nsteps = a.seg_rows;
+  for (int s = 0; s < nsteps; ++s) {
+    u32x4 y0 = {0u, 0u, 0u, 0u}, y1 = {0u, 0u, 0u, 0u};
+    if (bsum && s > 0) {
+      y0 = *reinterpret_cast<const u32x4*>(a.bs_y + piece_off(s - 1, 0));
+      y1 = *reinterpret_cast<const u32x4*>(a.bs_y + piece_off(s - 1, 1));
+    }
+    if (s + 1 < nsteps) issue_row(s + 2);
+    const char* row0 = smem + (s % 3) * ROWB + abase;
+    const char* row1 = smem + ((s + 1) % 3) * ROWB + abase;
+    char* sp = stage + (s & 1) * STAGEB + (16 * nb + n16) * 2;
+    // finish one class of one pixel block: bias, statistics, staging at output pixel (row pi, 2 b + pj)
+    auto finish = [&](const f32x4& acc, int b, int pi, int pj, int slot) {
+      float v[4], sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[e] + bias_n; sum += v[e]; }
+      if (a.table != nullptr) {
+        // Chan's update with equal batches of 4 (see march_s_kernel): batch number MBW s + b of this class
+        const float mb = sum * 0.25f;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float dlt = v[e] - mb; q += dlt * dlt; }
+        const int k = MBW * s + b;
+        const float f = 1.f / (float)(k + 1), d = mb - st_mean[slot];
+        st_mean[slot] += d * f;
+        st_m2[slot] += q + d * d * ((float)(4 * k) * f);
+        st_n[slot] = (float)(4 * (k + 1));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int bpx = 16 * (wm * MBW + b) + 4 * kq + e;
+        *reinterpret_cast<bf16_t*>(sp + (pi * 2 * WS + 2 * bpx + pj) * SPXB) = (bf16_t)v[e];
+      }
+    };
+    if (role == 0) {
+#pragma unroll
+      for (int b = 0; b < MBW; ++b) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+          for (int kk = 0; kk < KN; ++kk) {
+            const char* rp = (d >> 1) ? row1 : row0;
+            const bf16x8 af = *reinterpret_cast<const bf16x8*>(rp + b * 16 * PXB + (d & 1) * PXB + kk * 64);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[d * KN + kk], acc, 0, 0, 0);
+          }
+        finish(acc, b, 1, 1, 0);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < MBW; ++b) {
+        f32x4 c00 = {0.f, 0.f, 0.f, 0.f}, c01 = c00, c10 = c00;
+#pragma unroll
+        for (int kk = 0; kk < KN; ++kk) {
+          const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(row0 + b * 16 * PXB + kk * 64);
+          const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(row0 + b * 16 * PXB + PXB + kk * 64);
+          const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(row1 + b * 16 * PXB + kk * 64);
+          c00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[kk], c00, 0, 0, 0);
+          c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[KN + kk], c01, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[3 * KN + kk], c10, 0, 0, 0);
+          c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, bfrag[2 * KN + kk], c01, 0, 0, 0);
+          c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, bfrag[4 * KN + kk], c10, 0, 0, 0);
+        }
+        finish(c00, b, 0, 0, 0);
+        finish(c01, b, 0, 1, 1);
+        finish(c10, b, 1, 0, 2);
+      }
+    }
+    if (s > 0) store_tile(s - 1, y0, y1);
+    if (s + 1 < nsteps) write_row(s + 2);
+    __syncthreads();
+  }
+  {
+    u32x4 y0 = {0u, 0u, 0u, 0u}, y1 = {0u, 0u, 0u, 0u};
+    if (bsum) {
+      y0 = *reinterpret_cast<const u32x4*>(a.bs_y + piece_off(nsteps - 1, 0));
+      y1 = *reinterpret_cast<const u32x4*>(a.bs_y + piece_off(nsteps - 1, 1));
+    }
+    store_tile(nsteps - 1, y0, y1);
+  }
+
+  if (a.table != nullptr) {
+    // table [N][slots][4 classes][CO][2]; slot = (strip * nseg + seg) * NWM + wm; class index = 2 pi + pj
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (role == 0 && k > 0) break;
+      float nn = st_n[k], mm = st_mean[k], qq = st_m2[k];
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float n2 = __shfl_xor(nn, o), m2 = __shfl_xor(mm, o), q2 = __shfl_xor(qq, o);
+        chan_merge(nn, mm, qq, n2, m2, q2);
+      }
+      if (kq == 0) {
+        const int cls = role == 0 ? 3 : k;                       // role B: k = 0, 1, 2 = classes 00, 01, 10
+        const int slot = (strip * a.nseg + seg) * G::NWM + wm;
+        float* tp = a.table + 2 * ((((size_t)n * a.slots + slot) * 4 + cls) * CO + 16 * nb + n16);
+        tp[0] = mm * nn;
+        tp[1] = qq;
+      }
+    }
+  }
+  if (bsum) {
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                 // [tid][16] floats: 48 KiB over ring + staging
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[tid * 16 + e] = bs_a1[e]; red[tid * 16 + 8 + e] = bs_a2[e]; }
+    __syncthreads();
+    if (tid < 2 * CO) {
+      const int ch = tid >> 1, which = tid & 1, pc = ch >> 3, e = ch & 7;
+      float sum = 0.f;
+      for (int p = 0; p < 2 * WS; ++p) sum += red[(p * CPR + pc) * 16 + which * 8 + e];
+      a.bs_out[(((size_t)n * (a.strips * a.nseg) + strip * a.nseg + seg) * CO + ch) * 2 + which] = sum;
+    }
+  }
+}
+
 // segments per strip: enough workgroups for two rounds of the CUs when the plane allows, rows per segment >= 4
 int pick_segments(int N, int strips, int Ho) {
   const int cus = g_opt_cus > 0 ? g_opt_cus : device_cus();
@@ -336,66 +625,98 @@ int pick_segments(int N, int strips, int Ho) {
 namespace p2phd {
 
 // kind of marching kernel a layer's launch takes (0 = none).  which: 0 = forward, 1 = input gradient.
-//   1 = "S" 48 -> 96: Conv2d(48, 96, 3, s2, p1) forward, or the input gradient of ConvTranspose2d(96, 48, 3, s2, p1, op1)
+//   1 = "S" 48 -> 96 gather: Conv2d(48, 96, 3, s2, p1) forward; input gradient of ConvTranspose2d(96, 48, 3, s2, p1, op1)
+//   2 = "U" 96 -> 48 transposed form: that ConvTranspose2d's forward; that Conv2d's input gradient
 int march_kind(const p2phd_conv_desc* c, int which) {
   if (g_opt_march == 0 || c->dtype != P2PHD_BF16 || c->R != 3 || c->S != 3 || c->stride != 2 || c->pad != 1 || c->pad_mode != 0) return 0;
-  if (which == 0 && !c->transposed && c->C == 48 && c->K == 96 && c->H % 2 == 0 && c->W % 128 == 0 && c->H >= 8) return 1;
-  if (which == 1 && c->transposed && c->opad == 1 && c->C == 96 && c->K == 48 && c->W % 64 == 0 && c->H >= 4) return 1;
+  const bool conv = !c->transposed && c->C == 48 && c->K == 96 && c->H % 2 == 0 && c->W % 128 == 0 && c->H >= 8;
+  const bool convt = c->transposed && c->opad == 1 && c->C == 96 && c->K == 48 && c->W % 64 == 0 && c->H >= 4;
+  if (which == 0) return conv ? 1 : (convt ? 2 : 0);
+  if (which == 1) return convt ? 1 : (conv ? 2 : 0);
   return 0;
 }
 
+namespace {
+typedef SGeom<48, 96, 64> GS;
+typedef UGeom<96, 48, 64> GU;
+struct MarchGeom { int Hin, Win, Ho, Wo, strips, nseg, seg_rows; };
+// geometry of the launch: the S kernel marches over OUTPUT rows of its half-resolution plane, the U kernel over INPUT rows
+MarchGeom march_geom(const p2phd_conv_desc* c, int kind, int which) {
+  MarchGeom g{};
+  const bool conv = !c->transposed;                              // the layer is the Conv2d (else the ConvTranspose2d)
+  const int Hs = conv ? c->H / 2 : c->H, Ws = conv ? c->W / 2 : c->W;   // the 96-channel (small) plane
+  const int Hb = 2 * Hs, Wb = 2 * Ws;                            // the 48-channel (big) plane
+  (void)which;
+  if (kind == 1) { g.Hin = Hb; g.Win = Wb; g.Ho = Hs; g.Wo = Ws; }
+  else { g.Hin = Hs; g.Win = Ws; g.Ho = Hb; g.Wo = Wb; }
+  g.strips = Ws / 64;
+  g.nseg = pick_segments(c->N, g.strips, Hs);
+  g.seg_rows = Hs / g.nseg;
+  return g;
+}
+}  // namespace
+
 size_t march_packed_elems(const p2phd_conv_desc* c, int which) {
   const int kind = march_kind(c, which);
-  if (kind == 1) return (size_t)(96 / 16) * SGeom<48, 96, 64>::KS * 64 * 8;
+  if (kind == 1) return (size_t)(96 / 16) * GS::KS * 64 * 8;
+  if (kind == 2) return (size_t)GU::NB * (GU::FA + GU::FB) * 64 * 8;
   return 0;
 }
 
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st) {
   const int kind = march_kind(c, which);
-  if (kind == 1) {
-    // forward: Conv2d weight [K=96][C=48][3][3]; input gradient of ConvTranspose2d: weight [Cin=96][Cout=48][3][3]
-    const int total = (96 / 16) * SGeom<48, 96, 64>::KS * 64;
+  // both layers keep their weights as [96-side index][48-side index][3][3] or the reverse:
+  //   Conv2d(48, 96): [K = 96][C = 48][3][3];  ConvTranspose2d(96, 48): [Cin = 96][Cout = 48][3][3]  -- the same strides
+  if (kind == 1) {                                               // out = the 96 side (o), in = the 48 side (ci)
+    const int total = (96 / 16) * GS::KS * 64;
     hipLaunchKernelGGL((march_s_pack_kernel<48, 96>), dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, (long)48 * 9, (long)9);
+    return check_launch("march_pack");
+  }
+  if (kind == 2) {                                               // in = the 96 side (ci), out = the 48 side (o)
+    const int total = GU::NB * (GU::FA + GU::FB) * 64;
+    hipLaunchKernelGGL((march_u_pack_kernel<96, 48>), dim3((total + 255) / 256), dim3(256), 0, st, w, (bf16_t*)wf, (long)48 * 9, (long)9);
     return check_launch("march_pack");
   }
   set_error("march_pack: layer has no marching kernel");
   return P2PHD_EINVAL;
 }
 
-// geometry of the launch `march_run` will make: statistics slots per sample and rows per slot; fused-sums tiles per sample
-void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* slot_rows, int* bs_tiles) {
-  // output plane of the S kernel: forward -> (H/2, W/2); input gradient of the transposed layer -> its input (H, W)
-  const int Ho = which == 0 ? c->H / 2 : c->H, Wo = which == 0 ? c->W / 2 : c->W;
-  const int strips = Wo / 64;
-  const int nseg = pick_segments(c->N, strips, Ho);
-  if (slots) *slots = strips * nseg * SGeom<48, 96, 64>::NWM;
-  if (slot_rows) *slot_rows = (Ho / nseg) * (64 / SGeom<48, 96, 64>::NWM);
-  if (bs_tiles) *bs_tiles = strips * nseg;
+// geometry of the launch `march_run` will make: statistics slots per sample, classes per slot, pixels per (slot, class) and
+// per-class plane size (what launch_stats_merge needs); fused-sums partial rows per sample
+void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* ncls, int* slot_rows, long* npix_cls, int* bs_tiles) {
+  const int kind = march_kind(c, which);
+  const MarchGeom g = march_geom(c, kind, which);
+  const int nwm = kind == 1 ? GS::NWM : GU::NWM;
+  if (slots) *slots = g.strips * g.nseg * nwm;
+  if (ncls) *ncls = kind == 1 ? 1 : 4;
+  if (slot_rows) *slot_rows = g.seg_rows * (64 / nwm);
+  if (npix_cls) *npix_cls = kind == 1 ? (long)g.Ho * g.Wo : (long)g.Hin * g.Win;
+  if (bs_tiles) *bs_tiles = g.strips * g.nseg;
 }
 
 int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
               const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st) {
   const int kind = march_kind(c, which);
-  P2PHD_REQUIRE(kind == 1, "march_run: layer has no marching kernel");
-  typedef SGeom<48, 96, 64> G;
+  P2PHD_REQUIRE(kind == 1 || kind == 2, "march_run: layer has no marching kernel");
+  const MarchGeom g = march_geom(c, kind, which);
   MarchArgs a{};
   a.in = (const bf16_t*)in; a.wf = (const bf16_t*)wf; a.bias = bias; a.out = (bf16_t*)out; a.table = table;
-  a.N = c->N;
-  if (which == 0) { a.Hin = c->H; a.Win = c->W; a.Ho = c->H / 2; a.Wo = c->W / 2; }
-  else { a.Hin = 2 * c->H; a.Win = 2 * c->W; a.Ho = c->H; a.Wo = c->W; }     // gathers dy [N, 2H, 2W, 48], writes dx [N, H, W, 96]
-  a.strips = a.Wo / 64;
-  a.nseg = pick_segments(a.N, a.strips, a.Ho);
-  a.seg_rows = a.Ho / a.nseg;
-  a.slots = a.strips * a.nseg * G::NWM;
-  const size_t ib = (size_t)a.N * a.Hin * a.Win * 48 * 2;
+  a.N = c->N; a.Hin = g.Hin; a.Win = g.Win; a.Ho = g.Ho; a.Wo = g.Wo;
+  a.strips = g.strips; a.nseg = g.nseg; a.seg_rows = g.seg_rows;
+  a.slots = g.strips * g.nseg * (kind == 1 ? GS::NWM : GU::NWM);
+  const size_t ib = (size_t)a.N * a.Hin * a.Win * (kind == 1 ? 48 : 96) * 2;
   P2PHD_REQUIRE(ib < 0xFFFFFFF0ull, "march: tensor larger than 4 GiB");
   a.in_bytes = (unsigned)ib;
   a.bs_y = (const bf16_t*)bs_y; a.bs_stats = bs_stats; a.bs_out = bs_out;
   a.bs_inv_hw = bs_inv_hw; a.bs_eps = bs_eps; a.bs_slope = bs_slope;
-  auto kern = march_s_kernel<48, 96, 64>;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-  hipLaunchKernelGGL(kern, dim3((unsigned)(a.N * a.strips * a.nseg)), dim3(kThreads), G::LDS, st, a);
-  return check_launch("march_s");
+  const dim3 grid((unsigned)(a.N * a.strips * a.nseg));
+  auto launch = [&](auto kern, int lds, const char* what) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);
+    return check_launch(what);
+  };
+  if (kind == 1) return bs_out ? launch(march_s_kernel<48, 96, 64, true>, GS::LDS, "march_s") : launch(march_s_kernel<48, 96, 64, false>, GS::LDS, "march_s");
+  return bs_out ? launch(march_u_kernel<96, 48, 64, true>, GU::LDS, "march_u") : launch(march_u_kernel<96, 48, 64, false>, GU::LDS, "march_u");
 }
 
 }  // namespace p2phd

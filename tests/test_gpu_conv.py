@@ -398,7 +398,7 @@ def test_trunk_layer_at_baseline_size():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
-@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide", "head_to1", "march_conv_transpose"])
+@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide", "head_to1", "march_conv_transpose", "march_s2_conv"])
 def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, tol, monkeypatch):
     """p2phd_conv_dgrad_bsum: the input-gradient kernel of the consumer leaves the (sum g', sum g' yhat) of the producer's
     InstanceNorm backward, which then runs its apply pass only.  Same gradients as the two-pass form (P2PHD_BSUM=0) up to
@@ -410,7 +410,9 @@ def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, 
         C1 = 256
     if consumer == "march_conv_transpose":                         # bf16: the input gradient is the marching kernel (csrc/march.hip)
         C1, H, W = 96, 16, 64
-    c2 = {"march_conv_transpose": (C1, 48, 3, 2, 1, 0, True, 1), "s2_conv": (C1, 32, 3, 2, 1, 0, False, 0), "s1_conv": (C1, 40, 3, 1, 1, 0, False, 0),
+    if consumer == "march_s2_conv":                                # bf16: ... and here its transposed form
+        C1, H, W = 48, 16, 128
+    c2 = {"march_conv_transpose": (C1, 48, 3, 2, 1, 0, True, 1), "march_s2_conv": (C1, 96, 3, 2, 1, 0, False, 0), "s2_conv": (C1, 32, 3, 2, 1, 0, False, 0), "s1_conv": (C1, 40, 3, 1, 1, 0, False, 0),
           "conv_transpose": (C1, 16, 3, 2, 1, 0, True, 1), "s1_256wide": (C1, 256, 3, 1, 1, 0, False, 0),
           "head_to1": (C1, 1, 3, 1, 1, 0, False, 0)}[consumer]      # 1-channel head: output W-fold in front of the launch
     g = torch.Generator().manual_seed(11)

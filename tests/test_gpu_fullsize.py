@@ -460,14 +460,16 @@ def test_baseline_wording_g3l2_forward_full_size():
 
 
 def test_baseline_wording_g3l2_graphed_bf16_step_batch8():
-    """The same generator (nd3, nle2, nb9, nbl3) through one captured bf16 training step at batch 8 with the staged backward
-    of the data-parallel step (4 gradient buckets): the size-independent properties the configs[3] test checks."""
+    """The same generator (nd3, nle2, nb9, nbl3) through one captured bf16 training step at batch 8: the size-independent
+    properties the configs[3] test checks.  (Two enhancer stages put two forks into the backward graph; the staged backward
+    of the data-parallel exchange covers one -- LocalEnhancer.bucket_plan -- so this generator's gradients travel as one
+    bucket, exchanged beside the discriminator backward.)"""
     from pix2pixhdaudiosr_amd.models.models import create_model
     o = _opt(netG="local", n_downsample_global=3, n_blocks_global=9, n_local_enhancers=2, n_blocks_local=3, fp16=True, mask=True,
              grad_buckets=4)
     m = create_model(o)
     assert sum(p.numel() for p in m.netG.parameters()) == 413_049_986
-    assert m._bucket_plan()[0] == 4 and len(m._bucket_plan()[1]) == 3
+    assert m._bucket_plan()[1] == []                               # one stage
     T = 255 * 512
     gen = torch.Generator().manual_seed(5)
     hr = (0.1 * torch.randn(8, T, generator=gen)).cuda()

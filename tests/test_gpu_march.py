@@ -44,7 +44,7 @@ def test_marching_forward_equals_the_gather_gemm(geom):
     y0, g0 = _run(spec, x, w, b, cot, 0)
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 4e-3                     # two roundings of a bf16 store apart
     for a, c in zip(g1[:2], g0[:2]):                                               # (bias in front of InstanceNorm: noise on both sides)
-        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1.2e-2
+        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1.2e-2                  # input gradient: the "U" kernel vs the merged sub-pixel launch
 
 
 @pytest.mark.parametrize("geom", [(2, 8, 64), (1, 12, 128), (2, 256, 128)], ids=lambda g: "x".join(map(str, g)))
@@ -61,6 +61,6 @@ def test_marching_input_gradient_equals_the_gather_gemm(geom):
     cot = torch.randn(N, 48, 2 * H, 2 * W, generator=gen).cuda()
     y1, g1 = _run(spec, x, w, b, cot, 1)
     y0, g0 = _run(spec, x, w, b, cot, 0)
-    assert torch.equal(y1, y0)                                                     # the forward is the same kernel either way
-    assert rel_err(g1[0].cpu().numpy(), g0[0].cpu().numpy()) < 4e-3
-    assert rel_err(g1[1].cpu().numpy(), g0[1].cpu().numpy()) < 1e-6              # weight gradient: same kernel, same operands
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 4e-3                     # forward: the "U" kernel vs the merged sub-pixel launch
+    for a, c in zip(g1[:2], g0[:2]):                                               # input gradient: the "S" kernel vs the stride-2 gather-GEMM
+        assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1.2e-2

@@ -66,3 +66,6 @@ print(f"B={B}")
 layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "fwd")
 layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "dgrad")
 layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "dgrad+bsum")
+layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "fwd")
+layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "dgrad")
+layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "dgrad+bsum")

@@ -143,9 +143,11 @@ def main():
         tape._apply = counting
         with torch.no_grad():
             parts(d(pG), d(pD), lr_s.double(), hr_s.double(), oo)
-    print("# elements whose fp32 branch differs from the fp64 branch, per activation layer in execution order (G: 27 ReLU, then D(real), D(fake))")
-    for i, (nf, tot_el, shp) in enumerate(flips[:27]):
-        print(f"  G relu {i:2d} {str(shp):24s} {nf:8d} of {tot_el:10d} = {nf / tot_el:.2e}   sqrt(share) {(nf / tot_el) ** 0.5:.2e}")
+    n_g = 1 + 2 * oo.n_downsample_global + oo.n_blocks_global          # ReLUs of the generator: c7, down, one per block, up
+    print("# elements whose fp32 branch differs from the fp64 branch, per activation layer in execution order (G: 18 ReLU -- c7, 4 down, 9 blocks, 4 up --, then the LeakyReLUs of D(real), first 9 shown)")
+    for i, (nf, tot_el, shp) in enumerate(flips[:n_g + 9]):
+        name = f"G relu {i:2d}" if i < n_g else f"D(real) lrelu {i - n_g:2d}"
+        print(f"  {name:18s} {str(shp):24s} {nf:8d} of {tot_el:10d} = {nf / tot_el:.2e}   sqrt(share) {(nf / tot_el) ** 0.5:.2e}")
     # how much of the whole generator gradient each part is (fp64 norms), at the input layer and at the output layer
     tot = {k: g64["G_GAN"][k] + g64["G_GAN_Feat"][k] for k in keys}
     print("# share of each part in the norm of the whole generator gradient (fp64): first layer / last layer")
