@@ -760,7 +760,7 @@ class LossFn(torch.autograd.Function):
     gradient is zero on the other samples -- or, with park, only the [n0, n1) part exists and is parked."""
 
     @staticmethod
-    def forward(ctx, a, b, kind, target, coeff, channels, park=False, rows=None):
+    def forward(ctx, a, b, kind, target, coeff, channels, park=False, rows=None, into=None):
         gf = getattr(a, "grad_fn", None)
         ctx.park_src = gf if (park and gf is not None and hasattr(gf, "_p2phd_consumers") and hasattr(gf, "_parked")) else None
         if ctx.park_src is None:
@@ -770,12 +770,14 @@ class LossFn(torch.autograd.Function):
         if b is not None and tuple(b.shape) != tuple(av.shape):
             raise _lib.P2PHDError(f"loss: operand shapes differ: {tuple(av.shape)} vs {tuple(b.shape)}")
         P = av.numel() // av.shape[-1]
-        out = zeros((), a.device)
+        # `into` (LossAcc): the kernel ADDS its term to that accumulator (it always accumulates: a fresh slot is zero), and
+        # the tensor returned is only this term's handle in the autograd graph (LossSum wires the gradients)
+        out = zeros((), a.device) if into is None else into
         check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(av), ptr(b), float(target), P, channels, float(coeff),
                                    ptr(out), stream_ptr()), "loss_fwd")
         ctx.meta = (kind, float(target), float(coeff), channels, P, rows)
         ctx.a, ctx.b = a, b
-        return out
+        return out if into is None else out.detach()
 
     @staticmethod
     def backward(ctx, g):
@@ -800,8 +802,48 @@ class LossFn(torch.autograd.Function):
             # kernel (or the block itself does, if that kernel is not part of this backward pass); autograd gets nothing
             src = ctx.park_src
             src._parked = da if src._parked is None else src._parked + da
-            return None, None, None, None, None, None, None, None
-        return (da if da_full is None else da_full), None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None, None
+        return (da if da_full is None else da_full), None, None, None, None, None, None, None, None
+
+
+class LossSum(torch.autograd.Function):
+    """`total` = the accumulator the kernels of `terms` added into, as the autograd sum of those terms: no launch in either
+    direction (the reference's `loss += term` chains, pix2pixHD_model.py:391-398, networks.py:100-110, cost a kernel per term
+    and another per term in the backward pass).  One copy per loss instead."""
+
+    @staticmethod
+    def forward(ctx, total, *terms):
+        ctx.n = len(terms)
+        return total.detach().clone()          # (a copy: the accumulator is an arena slot, recycled by the next step's begin_step)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + (g,) * ctx.n
+
+
+class LossAcc:
+    """One scalar loss built from several terms (scales, feature levels): every term's kernel adds into one arena slot."""
+
+    def __init__(self, device):
+        self.slot = zeros((), device)
+        self.terms = []
+
+    def mse_const(self, a_phys, channels, target, rows=None):
+        self.terms.append(LossFn.apply(a_phys, None, 0, target, 1.0, channels, False, rows, self.slot))
+
+    def l1(self, a_phys, b_phys, channels, coeff=1.0, park=False):
+        self.terms.append(LossFn.apply(a_phys, b_phys.detach(), 1, 0.0, coeff, channels, park, None, self.slot))
+
+    def l1_halves(self, t_phys, channels, coeff=1.0, park=False):
+        n = t_phys.shape[0]
+        if n % 2:
+            raise _lib.P2PHDError("l1_halves_loss: the batch must hold two equal halves")
+        self.terms.append(LossFn.apply(t_phys, t_phys.detach()[:n // 2], 1, 0.0, coeff, channels, park, (n // 2, n), self.slot))
+
+    def total(self):
+        if not self.terms:
+            return 0
+        return LossSum.apply(self.slot, *self.terms)
 
 
 def mse_const_loss(a_phys, channels, target, rows=None):

@@ -285,11 +285,11 @@ class Pix2PixHDModel(BaseModel):
 
     @staticmethod
     def _gan(pred, target):
-        loss = 0
+        acc = _ops.LossAcc(pred[0][-1][0].device)                  # networks.py:100-110: sum over scales, one accumulator
         for scale in pred:
             t, c = scale[-1]
-            loss = loss + _ops.mse_const_loss(t, c, target)
-        return loss
+            acc.mse_const(t, c, target)
+        return acc.total()
 
     def discriminate_F(self, input_label, test_image, use_pool=False):
         return self.netD.forward(torch.cat((input_label, test_image.detach()), dim=1))
@@ -335,12 +335,13 @@ class Pix2PixHDModel(BaseModel):
             pred = self.netD.forward_physical(_ops.to_physical_pair(self.compute_dtype, lr_spectro, hr_spectro, sr_result),
                                               exclusive=True)
             self._pair_batch = 2 * B
-            loss_D_real = loss_D_fake = loss_G_GAN = 0
+            a_real, a_fake, a_gan = (_ops.LossAcc(self.device) for _ in range(3))
             for scale in pred:
                 t, c = scale[-1]
-                loss_D_real = loss_D_real + _ops.mse_const_loss(t, c, 1.0, rows=(0, B))
-                loss_D_fake = loss_D_fake + _ops.mse_const_loss(t, c, 0.0, rows=(B, 2 * B))
-                loss_G_GAN = loss_G_GAN + _ops.mse_const_loss(t, c, 1.0, rows=(B, 2 * B))
+                a_real.mse_const(t, c, 1.0, rows=(0, B))
+                a_fake.mse_const(t, c, 0.0, rows=(B, 2 * B))
+                a_gan.mse_const(t, c, 1.0, rows=(B, 2 * B))
+            loss_D_real, loss_D_fake, loss_G_GAN = a_real.total(), a_fake.total(), a_gan.total()
         elif share_fake_pass:
             pred_real = self._D(lr_spectro, hr_spectro)
             pred_fake = self._D(lr_spectro, sr_result)
@@ -363,15 +364,17 @@ class Pix2PixHDModel(BaseModel):
             feat_weights = 4.0 / (self.opt.n_layers_D + 1)
             D_weights = 1.0 / self.opt.num_D
             w_feat = D_weights * feat_weights * self.opt.lambda_feat
+            a_feat = _ops.LossAcc(self.device)
             for i in range(self.opt.num_D):
                 if pair:
                     for j in range(len(pred[i]) - 1):
                         t, c = pred[i][j]
-                        loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_halves_loss(t, c, w_feat, park=True)
+                        a_feat.l1_halves(t, c, w_feat, park=True)
                     continue
                 for j in range(len(pred_fake[i]) - 1):
                     (a, c), (b, _) = pred_fake[i][j], pred_real[i][j]
-                    loss_G_GAN_Feat = loss_G_GAN_Feat + _ops.l1_loss(a, b, c, w_feat, park=True)
+                    a_feat.l1(a, b, c, w_feat, park=True)
+            loss_G_GAN_Feat = a_feat.total()
 
         # TDAC frame-matching loss (pix2pixHD_model.py:408-415): the second half of frame t and the first half of frame
         # t+1, each under its window half, must coincide
