@@ -243,6 +243,17 @@ int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const fl
  * gradient into db instead of overwriting it.  Only for planes that take the two-pass form:
  * p2phd_instnorm_act_bwd_two_pass(dtype, N, HW, C) != 0 (small planes use a single register-resident launch). */
 int p2phd_instnorm_act_bwd_two_pass(int dtype, int N, int64_t HW, int C);
+/* Residual trunk (networks.py:231-252: ReflectionPad2d(1) + Conv2d 3x3 + InstanceNorm): the input gradient of such a conv reads
+ * dy plus the pair-sum rows / columns of the reflection's adjoint.  For planes that take the single-launch InstanceNorm backward
+ * the kernel that WRITES dy appends them: allocate dy with p2phd_conv_reflect_extras_elems(desc) extra elements right behind its
+ * N*H*W*Cp (0 = this layer / plane has no such form), hand the extras pointer (= dy + N*H*W*Cp) to p2phd_instnorm_act_bwd_rx
+ * (the single-launch backward: no bstats), and take the input gradient with p2phd_conv_dgrad_rx -- no expansion pass, no workspace.
+ * db / db_accumulate as in p2phd_instnorm_act_bwd_apply. */
+size_t p2phd_conv_reflect_extras_elems(const p2phd_conv_desc* c);
+int p2phd_instnorm_act_bwd_rx(int dtype, const void* g, const void* y, const float* stats, void* dy, float* db, int db_accumulate,
+                              int N, int H, int W, int C, float eps, int act, void* reflect_extras, void* stream);
+int p2phd_conv_dgrad_rx(const p2phd_conv_desc* c, const void* dy_with_extras, const void* packed_dgrad, const void* addend, void* dx,
+                        void* stream);
 int p2phd_instnorm_act_bwd_apply(int dtype, const void* g, const void* y, const float* stats, const float* bstats, void* dy,
                                  float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream);
 /* dx = g * act'(.) evaluated from the saved activation OUTPUT a (tanh, LeakyReLU, ReLU). */

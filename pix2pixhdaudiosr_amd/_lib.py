@@ -61,6 +61,9 @@ SIGNATURES = {
     "p2phd_instnorm_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd_acc": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_instnorm_act_bwd_two_pass": (_i32, [_i32, _i32, _i64, _i32]),
+    "p2phd_conv_reflect_extras_elems": (C.c_size_t, [_vp]),
+    "p2phd_instnorm_act_bwd_rx": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "p2phd_conv_dgrad_rx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_instnorm_act_bwd_apply": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "p2phd_act_bwd_db": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),

@@ -527,6 +527,7 @@ class ConvBlockFn(torch.autograd.Function):
                 raise _lib.P2PHDError("residual add is only fused behind InstanceNorm")
             out = y
         ctx.spec, ctx.d = spec, d
+        ctx.in_link = getattr(x, "_p2phd_pool_link", None)          # (armed by conv_block: grad mode is off in here)
         ctx.pair = _is_pair(x)
         ctx.skip_wgrad = _SKIP_WGRAD[0]
         ctx.has_bias = bias is not None
@@ -586,22 +587,44 @@ class ConvBlockFn(torch.autograd.Function):
         # Parameters owned by FlatAdam carry their gradient as a view of its flat buffer: the kernels then add into it
         # directly (p2phd_*_acc) and autograd gets None, which saves a temporary and a `grad += new` launch per parameter.
         direct = need_w and _direct_grad(weight) and (not ctx.has_bias or _direct_grad(ctx.bias))
+        # Lazily zeroed gradients (FlatAdam.zero_grad(lazy=True)): a parameter marked fresh holds stale values; its first
+        # gradient of the step OVERWRITES them (the non-accumulating entry points), later ones add -- no 410 MB memset per step
+        fresh = need_w and (getattr(weight, "_p2phd_fresh", False) or (ctx.has_bias and getattr(ctx.bias, "_p2phd_fresh", False)))
+        if fresh and not direct:
+            for q in (weight, ctx.bias):
+                if q is not None and q.grad is not None and getattr(q, "_p2phd_fresh", False):
+                    q.grad.zero_()
+        acc = direct and not fresh
+        if need_w:
+            weight._p2phd_fresh = False
+            if ctx.has_bias:
+                ctx.bias._p2phd_fresh = False
         gb = None
         if need_w and ctx.has_bias:
             gb = ctx.bias.grad if direct else empty((spec.cout,), torch.float32, y.device)
         gb_done = False
+        rx = None                                                  # reflection extras behind dy (p2phd_conv_dgrad_rx)
         if spec.norm:
-            dy = empty_like(y)
             bs, ctx._bs = ctx._bs, None
-            if bs is not None and g.data_ptr() == bs[1] and g._version == bs[2] and g.shape == y.shape:
+            want_gx = ctx.needs_input_grad[0] and id(spec) not in _BWD_SKIP_DGRAD_SPECS
+            n_rx = L.p2phd_conv_reflect_extras_elems(C.byref(d)) if (spec.pad_mode == 1 and want_gx and bs is None) else 0
+            if n_rx:
+                # residual trunk: the kernel that writes dy appends the pair-sum rows / columns its input-gradient GEMM reads
+                buf = empty((y.numel() + n_rx,), y.dtype, y.device)
+                dy, rx = buf[:y.numel()].view(y.shape), buf[y.numel():]
+                check(L.p2phd_instnorm_act_bwd_rx(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(dy), ptr(gb), 1 if acc else 0, N, Ho, Wo,
+                                                  spec.cout, IN_EPS, spec.act, ptr(rx), stream_ptr()), "instnorm_act_bwd_rx")
+            elif bs is not None and g.data_ptr() == bs[1] and g._version == bs[2] and g.shape == y.shape:
                 # the consumer's input-gradient kernel already summed (g', g' * yhat): apply pass only
-                check(L.p2phd_instnorm_act_bwd_apply(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bs[0]), ptr(dy), ptr(gb), 1 if direct else 0,
+                dy = empty_like(y)
+                check(L.p2phd_instnorm_act_bwd_apply(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bs[0]), ptr(dy), ptr(gb), 1 if acc else 0,
                                                      N, Ho * Wo, spec.cout, IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd_apply")
                 _BSUM_CALLS[0] += 1
             else:
+                dy = empty_like(y)
                 bstats = empty((N, Cp_out, 2), torch.float32, y.device)
                 # the bias gradient (column sums of dy) rides on the apply pass
-                bwd = L.p2phd_instnorm_act_bwd_acc if direct else L.p2phd_instnorm_act_bwd
+                bwd = L.p2phd_instnorm_act_bwd_acc if acc else L.p2phd_instnorm_act_bwd
                 check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
                           stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
@@ -612,7 +635,7 @@ class ConvBlockFn(torch.autograd.Function):
             dy = empty_like(y)
             if gb is not None:                                     # bias gradient rides on the activation-backward pass
                 check(L.p2phd_act_bwd_db(d.dtype, ptr(g), ptr(y), ptr(dy), N * Ho * Wo, spec.cout, spec.act, ptr(gb),
-                                         1 if direct else 0, stream_ptr()), "act_bwd_db")
+                                         1 if acc else 0, stream_ptr()), "act_bwd_db")
                 gb_done = True
             else:
                 check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
@@ -621,7 +644,7 @@ class ConvBlockFn(torch.autograd.Function):
         gx = gw = None
         if need_w:
             gw = weight.grad if direct else empty(tuple(weight.shape), torch.float32, y.device)
-            wgrad = L.p2phd_conv_wgrad_acc if direct else L.p2phd_conv_wgrad
+            wgrad = L.p2phd_conv_wgrad_acc if acc else L.p2phd_conv_wgrad
             dwd = d if w_layout(gw) == d.w_layout else spec.desc(d.N, d.H, d.W, y.dtype, w_layout(gw))   # layout of what is WRITTEN
             ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device)
             check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
@@ -639,6 +662,11 @@ class ConvBlockFn(torch.autograd.Function):
             addend = None
             if ctx.link is not None and ctx.link.role_of(ctx) == "a":
                 addend = ctx.link.take()
+            if ctx.in_link is not None:
+                pk = ctx.in_link.take()                            # gradient of x through the pooling branch (PoolLink)
+                if pk is not None:
+                    pk = pk if rng is None else pk[rng[0]:rng[1]]
+                    addend = pk if addend is None else addend + pk
             src = ctx.src
             if src is not None and src._parked is not None and src._p2phd_consumers == 1:
                 # feature-matching gradient of x parked by the loss: summed inside this kernel instead of by autograd
@@ -671,6 +699,8 @@ class ConvBlockFn(torch.autograd.Function):
                 check(L.p2phd_conv_dgrad_act(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(src_y), src.spec.act, ptr(wsf),
                                              stream_ptr()), "conv_dgrad_act")
                 src._dy_done = (gx.data_ptr(), gx._version)
+            elif rx is not None:
+                check(L.p2phd_conv_dgrad_rx(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), stream_ptr()), "conv_dgrad_rx")
             else:
                 check(L.p2phd_conv_dgrad(C.byref(d), ptr(dy), ptr(wp), ptr(addend), ptr(gx), ptr(ws), stream_ptr()), "conv_dgrad")
         if _BWD_TRACE[0] is not None:
@@ -710,6 +740,9 @@ def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False)
     """`exclusive`: x is the output of another conv_block and this call is its ONLY consumer (see _bsum_enabled)."""
     if link is not None and residual is None:
         link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
+    pool_link = getattr(x, "_p2phd_pool_link", None)
+    if pool_link is not None:
+        pool_link.conv_spec = spec if (x.requires_grad and torch.is_grad_enabled()) else None
     out = _tag_pair(ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive), x)
     if spec._q8_out is not None:                                    # e4m3 twin of this output for the next layer's fp8 forward
         out._p2phd_q8, spec._q8_out = spec._q8_out, None
@@ -720,9 +753,27 @@ def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False)
 # AvgPool2d(3, 2, 1, count_include_pad=False)
 # ------------------------------------------------------------------------------------------
 
+class PoolLink:
+    """Couples the two consumers of a discriminator scale's input (networks.py:311-331: the scale's first conv and the
+    AvgPool2d that feeds the next scale).  In backward the pooling branch runs first (its nodes were created later); it
+    parks its input gradient here and the conv's input-gradient kernel adds it as `addend` -- the sum autograd would
+    otherwise form with a pass of its own over the full-resolution 2B-sample tensor.  One link per forward call;
+    attached to the shared input tensor (`t._p2phd_pool_link`)."""
+
+    def __init__(self):
+        self.g = None
+        self.conv_spec = None         # set by the conv's forward when its input gradient can be wanted
+        self.taken = False            # the conv's backward has run: a pooling backward that comes later returns its gradient itself
+
+    def take(self):
+        g, self.g, self.taken = self.g, None, True
+        return g
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, channels):
+        ctx.link = getattr(x, "_p2phd_pool_link", None)
         x = phys(x, "avgpool input")
         N, H, W, Cp = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
@@ -741,8 +792,13 @@ class AvgPoolFn(torch.autograd.Function):
         if rng is not None:                                        # sample-range backward (backward_on_samples)
             lo, hi = rng
             check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
-            return dx, None
-        check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
+        else:
+            check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
+        link = ctx.link
+        if (link is not None and not link.taken and link.g is None and link.conv_spec is not None
+                and id(link.conv_spec) not in _BWD_SKIP_DGRAD_SPECS):
+            link.g = dx                                            # the sibling conv's input-gradient kernel adds it (PoolLink)
+            return None, None
         return dx, None
 
 

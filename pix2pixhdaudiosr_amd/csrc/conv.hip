@@ -172,7 +172,17 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
           if (ho == 1 && hi == 2) hi = Hr; else if (ho == Hr - 2 && hi == Hr - 3) hi = Hr + 1; else if (hi >= Hr) hi = -1;
           if (wo == 1 && wi == 2) wi = Wr; else if (wo == Wr - 2 && wi == Wr - 3) wi = Wr + 1; else if (wi >= Wr) wi = -1;
         }
-        if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (nn * Hin + hi) * Win + wi;
+        if (pad_mode == 3) {
+          // the same adjoint with dy left as the PLAIN [N, Hin, Win] tensor: the pair-sum rows / columns sit in an extras block
+          // behind it (written by the InstanceNorm backward that produced dy, norm.hip): rx_base + n * EX + entry
+          const int Hr = Hin, Wr = Win;
+          if (ho == 1 && hi == 2) hi = Hr; else if (ho == Hr - 2 && hi == Hr - 3) hi = Hr + 1; else if (hi >= Hr) hi = -1;
+          if (wo == 1 && wi == 2) wi = Wr; else if (wo == Wr - 2 && wi == Wr - 3) wi = Wr + 1; else if (wi >= Wr) wi = -1;
+          if (hi >= 0 && wi >= 0) {
+            if (hi < Hr && wi < Wr) off = (nn * Hr + hi) * Wr + wi;
+            else off = d.rx_base + nn * (2 * (Wr + 2) + 2 * Hr) + (hi >= Hr ? (hi - Hr) * (Wr + 2) + wi : 2 * (Wr + 2) + (wi - Wr) * Hr + hi);
+          }
+        } else if (hi >= 0 && hi < Hin && wi >= 0 && wi < Win) off = (nn * Hin + hi) * Win + wi;
       }
       tab[t * BM + r] = off;
       tb += TPR;
@@ -1973,7 +1983,8 @@ int launch_gconv(const GDesc& d_in, int dtype, const void* in, const void* wp, c
   GDesc d = d_in;
   {
     const size_t esz = dtype == P2PHD_FP8_INTERNAL ? 1 : (dtype == P2PHD_BF16 ? 2 : 4);
-    const size_t ib = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz;
+    size_t ib = (size_t)d.N * d.Hin * d.Win * d.Cp_in * esz;
+    if (d.pad_mode == 3) ib += (size_t)d.N * (2 * (d.Win + 2) + 2 * d.Hin) * d.Cp_in * esz;   // + the reflection extras behind the tensor
     const size_t wb = (size_t)round_up(d.cls_cp > 0 ? 4 * d.cls_cp : d.Cp_out, 128) * d.KK * esz;   // packed rows are padded to 128
     P2PHD_REQUIRE(ib < 0xFFFFFFF0ull && wb < 0xFFFFFFF0ull, "gconv: tensor larger than 4 GiB");
     d.in_bytes = (unsigned)ib;

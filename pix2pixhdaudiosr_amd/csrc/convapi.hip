@@ -504,6 +504,35 @@ extern "C" int p2phd_conv_fwd_fp8(const p2phd_conv_desc* c, const void* x8, cons
   return launch_stats_merge(table, stats, c->N, (int)((npix + slot_rows - 1) / slot_rows), 1, cpitch(c->K), c->K, npix, slot_rows, st);
 }
 
+// ---- reflect-padded 3x3 input gradient whose pair-sum rows / columns were written by the producer of dy ----------------
+namespace {
+bool reflect3x3_exact(const p2phd_conv_desc* c) {
+  return c->pad_mode == 1 && fold_mode(c) != FOLD_OUT && !c->transposed && c->R == 3 && c->S == 3 && c->pad == 1 && c->stride == 1 &&
+         c->H >= 4 && c->W >= 4 && !g_opt_reflect_generic;
+}
+}  // namespace
+
+extern "C" size_t p2phd_conv_reflect_extras_elems(const p2phd_conv_desc* c) {
+  if (check_desc(c) != P2PHD_OK || !reflect3x3_exact(c) || c->N == 0) return 0;
+  if (p2phd_instnorm_act_bwd_two_pass(c->dtype, c->N, (int64_t)c->H * c->W, c->K)) return 0;   // (only the single-launch backward appends them)
+  return (size_t)c->N * (2 * (c->W + 2) + 2 * c->H) * cpitch(c->K);
+}
+
+extern "C" int p2phd_conv_dgrad_rx(const p2phd_conv_desc* c, const void* dy, const void* wp, const void* addend, void* dx, void* stream) {
+  if (int rc = check_desc(c)) return rc;
+  if (c->N == 0) return P2PHD_OK;
+  P2PHD_REQUIRE(dy && wp && dx, "conv_dgrad_rx: null pointer");
+  P2PHD_REQUIRE(p2phd_conv_reflect_extras_elems(c) > 0, "conv_dgrad_rx: layer has no reflection-extras form (p2phd_conv_reflect_extras_elems)");
+  std::vector<Plan> plans, ex; WMap m;
+  make_plans(c, 1, plans, &m);
+  transposed_plans(c->N, c->H, c->W, c->K, c->H, c->W, c->C, c->R, c->S, 1, 1, ex);
+  P2PHD_REQUIRE(ex.size() == 1 && ex[0].d.KK == plans[0].d.KK && ex[0].rows_pad == plans[0].rows_pad, "conv_dgrad_rx: plan mismatch");
+  ex[0].d.pad_mode = 3;
+  ex[0].d.rx_base = c->N * c->H * c->W;                          // dy [N, H, W, Cp(K)], then the extras [N][2 (W + 2) + 2 H][Cp(K)]
+  return launch_gconv(ex[0].d, c->dtype, dy, static_cast<const char*>(wp) + plans[0].w_off * elem_size(c->dtype), nullptr, addend, dx,
+                      nullptr, (hipStream_t)stream);
+}
+
 extern "C" size_t p2phd_conv_dgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (check_desc(c) != P2PHD_OK) return 0;
   int Ho, Wo;

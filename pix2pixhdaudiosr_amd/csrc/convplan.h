@@ -8,7 +8,8 @@ namespace p2phd {
 struct GDesc {
   int N, Hin, Win, Cp_in;          // gathered tensor (NHWC, channel pitch Cp_in)
   int Hg, Wg;                      // GEMM-row grid per sample
-  int sh, sw, pad_mode;            // gather stride; 0 = zeros outside, 1 = reflect
+  int sh, sw, pad_mode;            // gather stride; 0 = zeros outside, 1 = reflect, 2 / 3 = adjoint of ReflectionPad2d(1) (see gconv_kernel)
+  int rx_base;                     // pad_mode 3: pixel index (from the tensor's first pixel) of the reflection extras block
   int Hout, Wout, Cp_out;          // written tensor
   int oh_mul, oh_off, ow_mul, ow_off;   // output lattice: (ho*oh_mul+oh_off, wo*ow_mul+ow_off)
   int Kout, KK, act;               // valid output channels, padded GEMM-K (row length of packed weights)

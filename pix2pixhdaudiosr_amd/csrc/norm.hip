@@ -275,7 +275,8 @@ __global__ __launch_bounds__(256) void in_act_bwd_apply_kernel(const T* __restri
 template <typename T, int ITERS, int CGN>
 __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                const float* __restrict__ stats, T* __restrict__ dy, int HW,
-                                                               int C, int Cp, float eps, int act, float* __restrict__ db) {
+                                                               int C, int Cp, float eps, int act, float* __restrict__ db,
+                                                               T* __restrict__ rx, int W) {
   constexpr int EPP = Elem<T>::EPP;
   // CGN piece columns x (256 / CGN) pixel slices per workgroup: CGN = 4 doubles the workgroups of a 64-channel block and
   // halves the registers a thread holds (the 8-column form ran 1.5 workgroups per CU on the trunk: latency-bound)
@@ -350,6 +351,43 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
         bsum[k] += to_f(oo[k]);
       }
       *reinterpret_cast<uint4*>(dy + base + (size_t)p * Cp) = ov;
+    }
+  }
+  if (rx != nullptr) {
+    // The conv this gradient belongs to sits behind ReflectionPad2d(1) (the residual trunk): its input-gradient GEMM reads dy
+    // plus the pair-sum rows / columns of the reflection's adjoint (conv.hip, pad_mode 3).  This workgroup has just written
+    // every pixel of its channels of the plane, so it appends them itself -- rx [N][2 (W + 2) + 2 H][Cp]: row H = dy[0] +
+    // dy[2], row H + 1 = dy[H-3] + dy[H-1] (W + 2 columns each, the last two being the column sums of those), then columns
+    // W = dy[:,0] + dy[:,2] and W + 1 = dy[:,W-3] + dy[:,W-1] for rows < H -- instead of a copy pass over the whole gradient.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this thread's dy stores have left (same CU reads them back below)
+    __syncthreads();
+    const int H = HW / W, EX = 2 * (W + 2) + 2 * H;
+    const T* dyn = dy + (size_t)n * HW * Cp;
+    for (int task = tid; task < EX * CGN; task += 256) {
+      const int e = task / CGN, pcx = blockIdx.x * CGN + (task - e * CGN);
+      if (pcx >= cpr) continue;
+      int hs[2], ws[2], nh = 1, nw = 1;
+      int r, c;                                                  // expanded coordinates of this entry
+      if (e < 2 * (W + 2)) { r = H + e / (W + 2); c = e % (W + 2); }
+      else { const int q = e - 2 * (W + 2); r = q % H; c = W + q / H; }
+      hs[0] = r; ws[0] = c;
+      if (r == H) { hs[0] = 0; hs[nh++] = 2; } else if (r == H + 1) { hs[0] = H - 3; hs[nh++] = H - 1; }
+      if (c == W) { ws[0] = 0; ws[nw++] = 2; } else if (c == W + 1) { ws[0] = W - 3; ws[nw++] = W - 1; }
+      float accx[EPP];
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) accx[k] = 0.f;
+      for (int a2 = 0; a2 < nh; ++a2)
+        for (int b2 = 0; b2 < nw; ++b2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(dyn + ((size_t)hs[a2] * W + ws[b2]) * Cp + pcx * EPP);
+          const T* vv = reinterpret_cast<const T*>(&v);
+#pragma unroll
+          for (int k = 0; k < EPP; ++k) accx[k] += to_f(vv[k]);
+        }
+      uint4 ov;
+      T* oo = reinterpret_cast<T*>(&ov);
+#pragma unroll
+      for (int k = 0; k < EPP; ++k) oo[k] = from_f<T>(accx[k]);
+      *reinterpret_cast<uint4*>(rx + ((size_t)n * EX + e) * Cp + pcx * EPP) = ov;
     }
   }
   if (db != nullptr) {                                          // uniform branch: all threads take it
@@ -799,11 +837,13 @@ extern "C" int p2phd_instnorm_act_bwd_two_pass(int dtype, int N, int64_t HW, int
 
 static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
                                  float* db, int db_accumulate, int N, int64_t HW, int C, float eps, int act, void* stream,
-                                 bool sums_given = false) {
+                                 bool sums_given = false, void* rx = nullptr, int W = 0) {
   const int Cp = (C + 7) & ~7;
   P2PHD_REQUIRE(Cp <= kMaxCp, "instnorm: at most %d channels", kMaxCp);
   if (N == 0 || HW == 0) return P2PHD_OK;
-  P2PHD_REQUIRE(g && y && stats && bstats && dy, "instnorm_act_bwd: null pointer");
+  P2PHD_REQUIRE(g && y && stats && (bstats || rx) && dy, "instnorm_act_bwd: null pointer");
+  P2PHD_REQUIRE(rx == nullptr || (bwd_single_launch(dtype, N, HW, C) && W >= 4 && HW % W == 0 && HW / W >= 4),
+                "instnorm_act_bwd_rx: reflection extras need a plane that takes the single-launch backward (p2phd_conv_reflect_extras_elems)");
   hipStream_t st = (hipStream_t)stream;
   if (db != nullptr && !db_accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
   const int epp = dtype == P2PHD_BF16 ? 8 : 4;
@@ -813,7 +853,7 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   P2PHD_REQUIRE(!sums_given || !bwd_single_launch(dtype, N, HW, C), "instnorm_act_bwd_apply: this plane takes the single-launch backward (p2phd_instnorm_act_bwd_two_pass)");
   if (bwd_single_launch(dtype, N, HW, C)) {
     dim3 fgrid((unsigned)cblocks4, (unsigned)N);
-#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db)
+#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db, (TT*)rx, W)
     if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 8); else P2PHD_FUSED_BWD(bf16_t, 10); }
     else if (dtype == P2PHD_F32) { if (HW <= 512) P2PHD_FUSED_BWD(float, 8); else P2PHD_FUSED_BWD(float, 10); }
     else { p2phd::set_error("instnorm_act_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }
@@ -851,6 +891,13 @@ extern "C" int p2phd_instnorm_act_bwd(int dtype, const void* g, const void* y, c
 extern "C" int p2phd_instnorm_act_bwd_acc(int dtype, const void* g, const void* y, const float* stats, float* bstats, void* dy,
                                           float* db, int N, int64_t HW, int C, float eps, int act, void* stream) {
   return instnorm_act_bwd_impl(dtype, g, y, stats, bstats, dy, db, 1, N, HW, C, eps, act, stream);
+}
+
+extern "C" int p2phd_instnorm_act_bwd_rx(int dtype, const void* g, const void* y, const float* stats, void* dy, float* db,
+                                         int db_accumulate, int N, int H, int W, int C, float eps, int act, void* reflect_extras,
+                                         void* stream) {
+  P2PHD_REQUIRE(reflect_extras != nullptr, "instnorm_act_bwd_rx: null extras pointer");
+  return instnorm_act_bwd_impl(dtype, g, y, stats, nullptr, dy, db, db_accumulate, N, (int64_t)H * W, C, eps, act, stream, false, reflect_extras, W);
 }
 
 extern "C" int p2phd_instnorm_act_bwd_apply(int dtype, const void* g, const void* y, const float* stats, const float* bstats,

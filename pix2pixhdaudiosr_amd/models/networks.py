@@ -546,6 +546,8 @@ class MultiscaleDiscriminator(_HipNet):
         comes from `_ops.l1_loss(..., park=True)` (Pix2PixHDModel._losses): the stages then form an exclusive chain."""
         result, cur = [], x
         for i in range(self.num_D):
+            if i != self.num_D - 1:
+                cur._p2phd_pool_link = _ops.PoolLink()              # `cur` feeds this scale's first conv AND the pooling below
             stages = self._scale_steps(self.num_D - 1 - i)          # reference networks.py:325
             feats, h = [], cur
             for j, st in enumerate(stages):

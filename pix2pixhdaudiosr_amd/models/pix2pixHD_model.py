@@ -435,8 +435,8 @@ class Pix2PixHDModel(BaseModel):
         ld = dict(zip(self.loss_names, losses))
         self._loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
         self._loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
-        self.optimizer_G.zero_grad()
-        self.optimizer_D.zero_grad()
+        self.optimizer_G.zero_grad(lazy=True)                       # (first weight gradient of the step overwrites: no memset)
+        self.optimizer_D.zero_grad(lazy=True)
         self.optimizer_G.bucket_log = []
         self.optimizer_D.bucket_log = []
         return ld

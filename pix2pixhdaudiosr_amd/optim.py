@@ -80,10 +80,31 @@ class FlatAdam(torch.optim.Optimizer):
                 p.grad = v
             p._p2phd_direct_grad = True                          # _ops.ConvBlockFn adds its weight gradients in place
 
-    def zero_grad(self, set_to_none=False):
-        # gradients stay views of the flat buffer; one memset instead of one per tensor
-        self.flat_g.zero_()
+    def zero_grad(self, set_to_none=False, lazy=False):
+        """Gradients stay views of the flat buffer.  Default: one memset instead of one per tensor.  `lazy` (the training
+        step): no memset at all -- every parameter is marked fresh, the conv blocks' first weight gradient of the step
+        overwrites it (_ops.ConvBlockFn.backward), and whatever is still fresh when the gradients are used (exchange,
+        update) is zeroed then (`_flush_fresh`)."""
         self._install_grad_views()
+        if lazy:
+            for p in self._params:
+                p._p2phd_fresh = True
+            self._lazy = True
+            return
+        self.flat_g.zero_()
+        for p in self._params:
+            p._p2phd_fresh = False
+        self._lazy = False
+
+    def _flush_fresh(self, start=0, stop=None):
+        """Zero the gradient of every parameter in [start, stop) that no backward pass has written since a lazy zero_grad."""
+        if not getattr(self, "_lazy", False):
+            return
+        stop = self._total if stop is None else stop
+        for p, o in zip(self._params, self._offs):
+            if getattr(p, "_p2phd_fresh", False) and start <= o < stop:
+                self.flat_g[o:o + p.numel()].zero_()
+                p._p2phd_fresh = False
 
     # ---- data parallel: one summing all-reduce of the whole gradient buffer over RCCL ----
     def enable_data_parallel(self, world_size, process_group=None, force_collectives=False):
@@ -100,6 +121,7 @@ class FlatAdam(torch.optim.Optimizer):
     def reduce_range_async(self, start, stop):
         """Start the summing all-reduce of flat_g[start:stop] (one bucket of a staged backward).  Buckets must not
         overlap; the launches are recorded in `bucket_log` (tests assert order and coverage)."""
+        self._flush_fresh(start, stop)
         if self._collectives and stop > start:
             from .parallel_state import all_reduce_flat_async
             if self._pending is None:
@@ -155,6 +177,7 @@ class FlatAdam(torch.optim.Optimizer):
     def step_local(self):
         """The update itself, without the data-parallel exchange (graph-capturable: every argument is constant)."""
         g = self.param_groups[0]
+        self._flush_fresh()
         self.sync_hyper()
         self.step_count += 1
         b1, b2 = g["betas"]

@@ -514,6 +514,49 @@ def test_reflect3x3_input_gradient_on_the_exact_grid_equals_padded_grid_form(sha
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(8, 256, 512, 8, 16), (16, 64, 512, 4, 5), (8, 128, 512, 20, 32)], ids=["8x16", "4x5", "20x32"])
+def test_reflection_extras_written_by_the_instancenorm_backward(geom, dtype, tol):
+    """Round 4: on planes that take the single-launch InstanceNorm backward (the residual trunk: 32 x 16), the kernel that
+    writes dy appends the pair-sum rows / columns the reflect-padded 3x3 input gradient reads (p2phd_instnorm_act_bwd_rx,
+    p2phd_conv_dgrad_rx: gather pad_mode 3) -- no expansion pass.  Whole block (ReflectionPad + Conv3x3 + InstanceNorm + ReLU)
+    forward / backward against the padded-grid + fold form (option reflect_generic, which has no extras form) and, in fp32,
+    against the oracle; planes down to 4 x 5 (rows 1 and H-2 neighbours)."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _lib.lib()
+    N, cin, cout, H, W = geom
+    gen = torch.Generator().manual_seed(H * 100 + W + cin)
+    x = torch.randn(N, cin, H, W, generator=gen)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) * 0.05
+    b = torch.randn(cout, generator=gen) * 0.1
+    cot = torch.randn(N, cout, H, W, generator=gen)
+    spec = _ops.ConvSpec(cin, cout, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, dtype)
+    assert L.p2phd_conv_reflect_extras_elems(C.byref(d)) == N * (2 * (W + 2) + 2 * H) * _ops.cpitch(cout)
+    outs = []
+    for generic in (0, 1):
+        _lib.check(L.p2phd_set_option(b"reflect_generic", generic))
+        try:
+            assert (L.p2phd_conv_reflect_extras_elems(C.byref(d)) > 0) == (generic == 0)
+            xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+            y = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(dtype, xd), wd, bd, spec), cout)
+            g = torch.autograd.grad((y * cot.cuda()).sum(), [xd, wd])
+            torch.cuda.synchronize()
+            outs.append((y.detach().cpu(), g[0].cpu(), g[1].cpu()))
+        finally:
+            _lib.check(L.p2phd_set_option(b"reflect_generic", 0))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert rel_err(outs[0][1].numpy(), outs[1][1].numpy()) < tol               # input gradient: extras form vs padded grid + fold
+    assert rel_err(outs[0][2].numpy(), outs[1][2].numpy()) < tol               # weight gradient: reads the plain part of dy
+    if dtype == torch.float32:
+        xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        yo = F.relu(F.instance_norm(F.conv2d(F.pad(xo, (1, 1, 1, 1), mode="reflect"), wo, b), eps=1e-5))
+        go = torch.autograd.grad((yo * cot).sum(), [xo, wo])
+        assert rel_err(outs[0][0].numpy(), yo.detach().numpy()) < 1e-4
+        assert rel_err(outs[0][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(outs[0][2].numpy(), go[1].numpy()) < 3e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
 def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypatch):
     """Producer without InstanceNorm (Conv + LeakyReLU, the discriminator's first layer): the exclusive consumer's
     input-gradient kernel multiplies dx by act'(x) (p2phd_conv_dgrad_act) and the producer skips its activation-backward
