@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
-# rocprofv3 evidence of one round (run on the GPU box: gpurun -- 'bash tools/collect_profiles.sh r03 [trace|pmc|all]').
+# rocprofv3 evidence of one round (run on the GPU box: gpurun -- 'bash tools/collect_profiles.sh r04 [trace|pmc|all]').
 # Every pass writes into a FRESH directory under gpurun_out/<tag>p/ (a failed pass must not be summarised from old files);
 # tools/summarize_profile.py turns the CSVs into the tracked files under profiles/.
 # The program after `--` is always python3 itself (no env / bash -c hop: the profiler has initialised the GPU by then).
 set -euo pipefail
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 WHAT="${2:-all}"
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Targets for the rocprofv3 --pmc passes (program directly after `--`): the three MFMA kernels the roofline talks about,
 ten launches each -- trunk forward (gconv 256x192), discriminator 256->512 forward (gconv 256x256), trunk weight gradient
-(wgrad_kernel<256>) -- at BASELINE configs[1] shapes, B = 32, bf16."""
+(wgrad_kernel<256>) -- and (round 4) the two marching kernels of the generator's outermost stride-2 layers, at BASELINE
+configs[1] shapes, B = 32, bf16."""
 import ctypes as C
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,12 +11,12 @@ from pix2pixhdaudiosr_amd import _ops
 
 L = _ops.lib()
 B = 32
-def layer(cin, cout, k, pad, pad_mode, H, W):
-    spec = _ops.ConvSpec(cin, cout, k, 1, pad, pad_mode, False, 0, True, 0)
+def layer(cin, cout, k, pad, pad_mode, H, W, stride=1, transposed=False):
+    spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, transposed, 1 if transposed else 0, True, 0)
     d = spec.desc(B, H, W, torch.bfloat16)
     Ho, Wo = spec.out_size(d)
     x = torch.randn(B, H, W, cin, device="cuda").to(torch.bfloat16)
-    w = torch.randn(cout, cin, k, k, device="cuda") * 0.02
+    w = torch.randn((cin, cout, k, k) if transposed else (cout, cin, k, k), device="cuda") * 0.02
     y = torch.empty(B, Ho, Wo, cout, device="cuda", dtype=torch.bfloat16)
     dy = torch.randn_like(y)
     stats = torch.zeros(B, cout, 2, device="cuda")
@@ -29,7 +30,9 @@ def layer(cin, cout, k, pad, pad_mode, H, W):
 
 t_fwd, t_wg = layer(768, 768, 3, 1, 1, 32, 16)
 d_fwd, _ = layer(256, 512, 4, 2, 0, 65, 33)
-for f in (t_fwd, d_fwd, t_wg):
+m_s, _ = layer(48, 96, 3, 1, 0, 512, 256, stride=2)
+m_u, _ = layer(96, 48, 3, 1, 0, 256, 128, stride=2, transposed=True)
+for f in (t_fwd, d_fwd, t_wg, m_s, m_u):
     for _ in range(10):
         f()
     torch.cuda.synchronize()

@@ -31,7 +31,7 @@ def pmc(paths, out):
                 acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
     res = {}
     for k, cs in acc.items():
-        if not any(t in k for t in ("gconv_kernel", "wgrad_kernel")):
+        if not any(t in k for t in ("gconv_kernel", "wgrad_kernel", "march_")):
             continue
         res[k] = {c: {"mean": statistics.mean(v), "n": len(v)} for c, v in cs.items()}
     json.dump(res, open(out, "w"), indent=1)
@@ -39,7 +39,9 @@ def pmc(paths, out):
 
 LABELS = (("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2", "gconv_kernel<bf16,256,192,2,3,2> trunk Conv3x3 768->768 @32x16 B=32 forward"),
           ("gconv_kernelIDF16bLi256ELi256ELi4ELi2ELi2", "gconv_kernel<bf16,256,256,4,2,2> discriminator Conv4x4 256->512 @65x33 B=32 forward"),
-          ("wgrad_kernelIDF16bLi256", "wgrad_kernel<bf16,256> trunk weight gradient 768x6912, 16384 pixels"))
+          ("wgrad_kernelIDF16bLi256", "wgrad_kernel<bf16,256> trunk weight gradient 768x6912, 16384 pixels"),
+          ("march_s_kernel<48, 96, 64, false>", "march_s_kernel<48,96,64> Conv3x3 s2 48->96 @512x256 B=32 forward (marching, round 4)"),
+          ("march_u_kernel<96, 48, 64, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"))
 
 
 def derive(paths, out, trunk_out):
@@ -116,7 +118,7 @@ def traffic(fetch_csv, write_csv, steps, out):
                 f"--warmup 1 --no-graph --no-probes --no-cpu-baseline --no-mdct` ({steps} step-equivalents per pass); FETCH_SIZE x2 (gfx950 counts 64 B per "
                 "128-B request), WRITE_SIZE as is; Infinity-Cache hits included (upper bounds on HBM traffic); times are those of the "
                 "instrumented FETCH pass.\n\n"
-                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22; round 2: 76.5 + 19.8).\n\n"
+                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22; round 2: 76.5 + 19.8; round 3: 73.5 + 19.7).\n\n"
                 "| kernel | launches/step | read GB/step | written GB/step | time ms/step |\n|---|---|---|---|---|\n")
         for k, v in rows[:40]:
             f.write(f"| `{k[-70:]}` | {v[0] / steps:.1f} | {2 * v[1] * 1024 / steps / 1e9:.2f} | {v[2] * 1024 / steps / 1e9:.2f} | {v[3] / steps / 1e6:.2f} |\n")
@@ -160,8 +162,8 @@ def one_step(path, out):
     print("wrote", out, f"{b - a} launches {tot / 1e3:.2f} ms")
 
 
-ROUND_TAG = "r03"
-ROUND = "round 3"
+ROUND_TAG = "r04"
+ROUND = "round 4"
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
