@@ -297,6 +297,23 @@ int p2phd_adam_step(float* params, const float* grads, float* exp_avg, float* ex
 int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
                         int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* Lazily normalised input (round 4; networks.py:190-195 and :205-207: the generator's outermost stride-2 layers at ngf 48, bf16).
+ * p2phd_conv_lazy_ok(desc) = 1: this layer's forward and weight gradient can take `x_raw`, the PRE-normalisation output of the
+ * InstanceNorm block in front of it, with that block's statistics [N][Cp][2] (mean, sum of squared deviations), activation and
+ * eps, and apply (x - mean) * rstd + activation while staging rows -- the p2phd_instnorm_act_fwd pass over that plane is not run.
+ * Results equal those computed from the materialised tensor, bit for bit.  Other arguments as p2phd_conv_fwd / p2phd_conv_wgrad
+ * (`accumulate`: 0 = overwrite dw / db, 1 = add). */
+int p2phd_conv_lazy_ok(const p2phd_conv_desc* c);
+int p2phd_conv_fwd_lazy(const p2phd_conv_desc* c, const void* x_raw, const float* x_stats, int x_act, float x_eps,
+                        const void* packed_fwd, const float* bias, void* y, float* stats, void* workspace, void* stream);
+int p2phd_conv_wgrad_lazy(const p2phd_conv_desc* c, const void* x_raw, const float* x_stats, int x_act, float x_eps,
+                          const void* dy, float* dw, float* db, int accumulate, void* workspace, void* stream);
+
+/* base[off, off + len) = 0 for n (off, len) pairs of int64 in DEVICE memory: one launch for the small segments of a flat
+ * gradient buffer (the bias gradients, which several kernels add into; the weight gradients are overwritten by their first
+ * writer of the step: p2phd_conv_wgrad vs p2phd_conv_wgrad_acc). */
+int p2phd_zero_segments(float* base, const int64_t* seg_dev, int n, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Spectrogram codec (csrc/spectro.hip): Pix2PixHDModel.to_spectro / denormalize / to_audio with
  * explicit_encoding (pix2pixHD_model.py:142-249).

@@ -64,6 +64,9 @@ SIGNATURES = {
     "p2phd_conv_reflect_extras_elems": (C.c_size_t, [_vp]),
     "p2phd_instnorm_act_bwd_rx": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
     "p2phd_conv_dgrad_rx": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_lazy_ok": (_i32, [_vp]),
+    "p2phd_conv_fwd_lazy": (_i32, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "p2phd_conv_wgrad_lazy": (_i32, [_vp, _vp, _vp, _i32, _f32, _vp, _vp, _vp, _i32, _vp, _vp]),
     "p2phd_instnorm_act_bwd_apply": (_i32, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _f32, _i32, _vp]),
     "p2phd_act_bwd": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _vp]),
     "p2phd_act_bwd_db": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
@@ -76,6 +79,7 @@ SIGNATURES = {
     "p2phd_loss_bwd": (_i32, [_i32, _i32, _vp, _vp, _f32, _i64, _i32, _f32, _vp, _vp, _vp]),
     "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
+    "p2phd_zero_segments": (_i32, [_vp, _vp, _i32, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_encode_ex": (_i32, [_vp, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -375,6 +375,7 @@ def to_physical_pair(dtype, a, b_real, b_fake):
 class FromPhysical(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_phys, channels):
+        _no_lazy(x_phys, "FromPhysical")
         _note_consumer(x_phys)
         ctx.meta = (x_phys.dtype, x_phys.shape[-1])
         return from_physical(x_phys, channels)
@@ -480,9 +481,44 @@ def _note_consumer(t):
     return gf
 
 
+# Lazily normalised activations (round 4).  A conv block asked to `defer` returns its RAW conv output tagged with a LazyNorm
+# (statistics, activation, channels): the consumer -- a layer whose forward and weight gradient stage their input through
+# registers (csrc/march.hip; p2phd_conv_lazy_ok) -- applies (y - mean) * rstd + activation on load, and the InstanceNorm
+# forward pass over that plane (a read and a write of the whole tensor) never runs.  Same values, bit for bit.  Any other
+# consumer materialises the tensor first (`materialise`): deferring is always safe, only sometimes useless, so
+# networks._run asks for it exactly where the next step is such a layer.
+class LazyNorm:
+    __slots__ = ("stats", "act", "channels", "gen")
+
+    def __init__(self, stats, act, channels, gen):
+        self.stats, self.act, self.channels, self.gen = stats, act, channels, gen
+
+
+_LAST_LAZY = [None]        # hand-over from ConvBlockFn.forward (which cannot tag its own output) to conv_block
+
+
+def lazy_static_ok(spec):
+    """Shape rule of p2phd_conv_lazy_ok without the geometry (the library checks the rest on every call)."""
+    return (spec.k == 3 and spec.stride == 2 and spec.pad == 1 and spec.pad_mode == 0 and not spec.fp8 and
+            ((not spec.transposed and spec.cin == 48 and spec.cout == 96) or
+             (spec.transposed and spec.opad == 1 and spec.cin == 96 and spec.cout == 48)))
+
+
+def materialise(x):
+    """The normalised + activated tensor a LazyNorm-tagged raw output stands for (p2phd_instnorm_act_fwd)."""
+    lz = getattr(x, "_p2phd_lazy", None)
+    if lz is None:
+        return x
+    N, H, W, _ = x.shape
+    out = empty_like(x)
+    check(lib().p2phd_instnorm_act_fwd(dt_code(x.dtype), ptr(x), ptr(lz.stats), None, ptr(out), N, H * W, lz.channels, IN_EPS,
+                                       lz.act, stream_ptr()), "instnorm_act_fwd")
+    return out
+
+
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, residual, spec, link=None, exclusive=False):
+    def forward(ctx, x, weight, bias, residual, spec, link=None, exclusive=False, defer=False):
         src = _note_consumer(x)
         if not exclusive:
             src = None
@@ -496,6 +532,9 @@ class ConvBlockFn(torch.autograd.Function):
         Ho, Wo = spec.out_size(d)
         L = lib()
         Cp_out = cpitch(spec.cout)
+        lazy_in = getattr(x, "_p2phd_lazy", None)
+        if lazy_in is not None and not (x.dtype == torch.bfloat16 and (spec.norm or spec.act == ACT_NONE) and L.p2phd_conv_lazy_ok(C.byref(d))):
+            x, lazy_in = materialise(x), None                      # this layer cannot normalise on load after all
         x8 = getattr(x, "_p2phd_q8", None) if (spec.fp8 and x.dtype == torch.bfloat16) else None
         wp = spec.packed_fp8(weight, d) if x8 is not None else spec.packed(weight, 0, d)
         b = None if bias is None else bias.detach().float().contiguous()
@@ -507,9 +546,17 @@ class ConvBlockFn(torch.autograd.Function):
         if x8 is not None:
             _FP8_CALLS[0] += 1
             check(L.p2phd_conv_fwd_fp8(C.byref(d), ptr(x8), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd_fp8")
+        elif lazy_in is not None:
+            check(L.p2phd_conv_fwd_lazy(C.byref(d), ptr(x), ptr(lazy_in.stats), lazy_in.act, IN_EPS, ptr(wp), ptr(b), ptr(y), ptr(stats),
+                                        ptr(ws), stream_ptr()), "conv_fwd_lazy")
         else:
             check(L.p2phd_conv_fwd(C.byref(d), ptr(x), ptr(wp), ptr(b), fused_act, ptr(y), ptr(stats), ptr(ws), stream_ptr()), "conv_fwd")
-        if spec.norm:
+        _LAST_LAZY[0] = None
+        if spec.norm and defer and residual is None and not spec.emit_q8:
+            # the consumer normalises on load: hand out the raw output, tagged by conv_block
+            out = y
+            _LAST_LAZY[0] = LazyNorm(stats, spec.act, spec.cout, arena_generation(x.device))
+        elif spec.norm:
             if _STATS_TRACE[0] is not None:
                 _STATS_TRACE[0].append((spec, stats.detach().clone(), Ho * Wo))
             res = None if residual is None else phys(residual, "residual")
@@ -533,6 +580,7 @@ class ConvBlockFn(torch.autograd.Function):
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.x, ctx.y, ctx.stats, ctx.weight, ctx.bias = x, y, stats, weight, bias
+        ctx.x_lazy = lazy_in                                       # x is RAW: the weight gradient normalises it on load too
         ctx.link = link
         ctx.arena_gen = arena_generation(x.device) if spec.norm else 0
         ctx._p2phd_consumers = 0                                   # forward calls that read `out` (see _note_consumer)
@@ -589,16 +637,14 @@ class ConvBlockFn(torch.autograd.Function):
         direct = need_w and _direct_grad(weight) and (not ctx.has_bias or _direct_grad(ctx.bias))
         # Lazily zeroed gradients (FlatAdam.zero_grad(lazy=True)): a parameter marked fresh holds stale values; its first
         # gradient of the step OVERWRITES them (the non-accumulating entry points), later ones add -- no 410 MB memset per step
-        fresh = need_w and (getattr(weight, "_p2phd_fresh", False) or (ctx.has_bias and getattr(ctx.bias, "_p2phd_fresh", False)))
-        if fresh and not direct:
-            for q in (weight, ctx.bias):
-                if q is not None and q.grad is not None and getattr(q, "_p2phd_fresh", False):
-                    q.grad.zero_()
-        acc = direct and not fresh
+        # (biases are zeroed eagerly by that zero_grad -- one launch for all of them -- and always accumulate)
+        fresh = need_w and getattr(weight, "_p2phd_fresh", False)
+        if fresh and not direct and weight.grad is not None:
+            weight.grad.zero_()
+        acc = direct and not fresh                                 # weight gradient: add (else overwrite)
+        acc_b = direct                                             # bias gradient: always add into the flat buffer
         if need_w:
             weight._p2phd_fresh = False
-            if ctx.has_bias:
-                ctx.bias._p2phd_fresh = False
         gb = None
         if need_w and ctx.has_bias:
             gb = ctx.bias.grad if direct else empty((spec.cout,), torch.float32, y.device)
@@ -612,19 +658,19 @@ class ConvBlockFn(torch.autograd.Function):
                 # residual trunk: the kernel that writes dy appends the pair-sum rows / columns its input-gradient GEMM reads
                 buf = empty((y.numel() + n_rx,), y.dtype, y.device)
                 dy, rx = buf[:y.numel()].view(y.shape), buf[y.numel():]
-                check(L.p2phd_instnorm_act_bwd_rx(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(dy), ptr(gb), 1 if acc else 0, N, Ho, Wo,
+                check(L.p2phd_instnorm_act_bwd_rx(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(dy), ptr(gb), 1 if acc_b else 0, N, Ho, Wo,
                                                   spec.cout, IN_EPS, spec.act, ptr(rx), stream_ptr()), "instnorm_act_bwd_rx")
             elif bs is not None and g.data_ptr() == bs[1] and g._version == bs[2] and g.shape == y.shape:
                 # the consumer's input-gradient kernel already summed (g', g' * yhat): apply pass only
                 dy = empty_like(y)
-                check(L.p2phd_instnorm_act_bwd_apply(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bs[0]), ptr(dy), ptr(gb), 1 if acc else 0,
+                check(L.p2phd_instnorm_act_bwd_apply(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bs[0]), ptr(dy), ptr(gb), 1 if acc_b else 0,
                                                      N, Ho * Wo, spec.cout, IN_EPS, spec.act, stream_ptr()), "instnorm_act_bwd_apply")
                 _BSUM_CALLS[0] += 1
             else:
                 dy = empty_like(y)
                 bstats = empty((N, Cp_out, 2), torch.float32, y.device)
                 # the bias gradient (column sums of dy) rides on the apply pass
-                bwd = L.p2phd_instnorm_act_bwd_acc if acc else L.p2phd_instnorm_act_bwd
+                bwd = L.p2phd_instnorm_act_bwd_acc if acc_b else L.p2phd_instnorm_act_bwd
                 check(bwd(d.dtype, ptr(g), ptr(y), ptr(stats), ptr(bstats), ptr(dy), ptr(gb), N, Ho * Wo, spec.cout, IN_EPS, spec.act,
                           stream_ptr()), "instnorm_act_bwd")
             gb_done = gb is not None
@@ -635,7 +681,7 @@ class ConvBlockFn(torch.autograd.Function):
             dy = empty_like(y)
             if gb is not None:                                     # bias gradient rides on the activation-backward pass
                 check(L.p2phd_act_bwd_db(d.dtype, ptr(g), ptr(y), ptr(dy), N * Ho * Wo, spec.cout, spec.act, ptr(gb),
-                                         1 if acc else 0, stream_ptr()), "act_bwd_db")
+                                         1 if acc_b else 0, stream_ptr()), "act_bwd_db")
                 gb_done = True
             else:
                 check(L.p2phd_act_bwd(d.dtype, ptr(g), ptr(y), ptr(dy), y.numel(), spec.act, stream_ptr()), "act_bwd")
@@ -647,7 +693,17 @@ class ConvBlockFn(torch.autograd.Function):
             wgrad = L.p2phd_conv_wgrad_acc if acc else L.p2phd_conv_wgrad
             dwd = d if w_layout(gw) == d.w_layout else spec.desc(d.N, d.H, d.W, y.dtype, w_layout(gw))   # layout of what is WRITTEN
             ws = workspace(L.p2phd_conv_wgrad_workspace_bytes(C.byref(dwd)), y.device)
-            check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
+            if ctx.x_lazy is not None:
+                lz = ctx.x_lazy
+                if lz.gen and lz.gen != (_ARENA.get(str(y.device)) or {}).get("gen", 0):
+                    raise _lib.P2PHDError("the InstanceNorm statistics of this layer's lazily normalised input were recycled: a new "
+                                          "training-step forward started before this backward ran")
+                if rng is not None:
+                    raise _lib.P2PHDError("sample-range backward through a lazily normalised input is not supported")
+                check(L.p2phd_conv_wgrad_lazy(C.byref(dwd), ptr(x), ptr(lz.stats), lz.act, IN_EPS, ptr(dy), ptr(gw),
+                                              None if gb_done else ptr(gb), 1 if acc else 0, ptr(ws), stream_ptr()), "conv_wgrad_lazy")
+            else:
+                check(wgrad(C.byref(dwd), ptr(x), ptr(dy), ptr(gw), None if gb_done else ptr(gb), ptr(ws), stream_ptr()), "conv_wgrad")
             if direct:
                 gw = gb = None
         gx_full = None
@@ -710,7 +766,7 @@ class ConvBlockFn(torch.autograd.Function):
             raise _lib.P2PHDError("sample-range backward through a residual block is not supported")
         if gres is not None and ctx.link is not None and ctx.link.park(gres, ctx):
             gres = None
-        return gx_full, gw, gb, gres, None, None, None
+        return gx_full, gw, gb, gres, None, None, None, None
 
 
 class SkipLink:
@@ -736,14 +792,18 @@ class SkipLink:
         return g
 
 
-def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False):
-    """`exclusive`: x is the output of another conv_block and this call is its ONLY consumer (see _bsum_enabled)."""
+def conv_block(x, weight, bias, spec, residual=None, link=None, exclusive=False, defer=False):
+    """`exclusive`: x is the output of another conv_block and this call is its ONLY consumer (see _bsum_enabled).
+    `defer`: the ONLY consumer of this block's output is a layer that normalises on load (lazy_static_ok): return the raw
+    conv output tagged with its LazyNorm instead of running the InstanceNorm forward pass."""
     if link is not None and residual is None:
         link.armed = bool(x.requires_grad) and torch.is_grad_enabled()
     pool_link = getattr(x, "_p2phd_pool_link", None)
     if pool_link is not None:
         pool_link.conv_spec = spec if (x.requires_grad and torch.is_grad_enabled()) else None
-    out = _tag_pair(ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive), x)
+    out = _tag_pair(ConvBlockFn.apply(x, weight, bias, residual, spec, link, exclusive, defer), x)
+    if _LAST_LAZY[0] is not None:
+        out._p2phd_lazy, _LAST_LAZY[0] = _LAST_LAZY[0], None
     if spec._q8_out is not None:                                    # e4m3 twin of this output for the next layer's fp8 forward
         out._p2phd_q8, spec._q8_out = spec._q8_out, None
     return out
@@ -770,11 +830,18 @@ class PoolLink:
         return g
 
 
+def _no_lazy(t, what):
+    if getattr(t, "_p2phd_lazy", None) is not None:
+        raise _lib.P2PHDError(f"{what}: got a lazily normalised (raw) conv output; only the next conv block of a chain may consume it "
+                              "(conv_block(..., defer=True))")
+    return t
+
+
 class AvgPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, channels):
         ctx.link = getattr(x, "_p2phd_pool_link", None)
-        x = phys(x, "avgpool input")
+        x = phys(_no_lazy(x, "avgpool"), "avgpool input")
         N, H, W, Cp = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = empty((N, Ho, Wo, Cp), x.dtype, x.device)
@@ -821,7 +888,7 @@ class LossFn(torch.autograd.Function):
         ctx.park_src = gf if (park and gf is not None and hasattr(gf, "_p2phd_consumers") and hasattr(gf, "_parked")) else None
         if ctx.park_src is None:
             _note_consumer(a)
-        a = phys(a, "loss input")
+        a = phys(_no_lazy(a, "loss"), "loss input")
         av = a if rows is None else a[rows[0]:rows[1]]
         if b is not None and tuple(b.shape) != tuple(av.shape):
             raise _lib.P2PHDError(f"loss: operand shapes differ: {tuple(av.shape)} vs {tuple(b.shape)}")

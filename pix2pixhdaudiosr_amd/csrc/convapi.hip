@@ -737,7 +737,12 @@ extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   size_t extra = 0;
   if (w.fold == FOLD_OUT) extra = folded_dy_bytes(c, Ho, Wo);
   else if (w.fold == FOLD_IN) extra = folded_x_bytes(c, Wo);
-  return w.dwp_bytes + extra;
+  // (the marching weight-gradient kernel keeps one slab per workgroup; sized for it whatever the option says at the moment)
+  const int keep = g_opt_march;
+  g_opt_march = 1;
+  const size_t mw = align256(march_w_workspace_floats(c) * sizeof(float));
+  g_opt_march = keep;
+  return std::max(w.dwp_bytes + extra, mw);
 }
 
 static int conv_wgrad_impl(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db, int accumulate,
@@ -747,6 +752,11 @@ static int conv_wgrad_impl(const p2phd_conv_desc* c, const void* x, const void* 
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   hipStream_t st = (hipStream_t)stream;
+  if (c->dtype == P2PHD_BF16 && march_w_ok(c)) {                  // the generator's outermost stride-2 layers (march.hip)
+    if (int rc = march_w_run(c, x, dy, dw, accumulate, nullptr, 1.f, 0.f, static_cast<float*>(workspace), st)) return rc;
+    if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, accumulate, st);
+    return P2PHD_OK;
+  }
   if (thin_wgrad_kind(c)) {                                       // dedicated kernel for the <= 4-channel layers (thinwgrad.hip)
     if (int rc = thin_wgrad(c, x, dy, dw, accumulate, static_cast<float*>(workspace), st)) return rc;
     if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, accumulate, st);
@@ -781,4 +791,51 @@ extern "C" int p2phd_conv_wgrad(const p2phd_conv_desc* c, const void* x, const v
 extern "C" int p2phd_conv_wgrad_acc(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, float* db,
                                     void* workspace, void* stream) {
   return conv_wgrad_impl(c, x, dy, dw, db, 1, workspace, stream);
+}
+
+
+// ---- lazily normalised input (round 4) ---------------------------------------------------------------------------------
+// A layer whose forward and weight gradient run on the marching kernels can take the RAW output of the InstanceNorm block in
+// front of it (pre-normalisation y + its statistics) and apply (y - mean) * rstd and the activation while it stages rows:
+// the p2phd_instnorm_act_fwd pass over that plane never runs.  Values are those of the materialised form, bit for bit.
+extern "C" int p2phd_conv_lazy_ok(const p2phd_conv_desc* c) {
+  if (c == nullptr || check_desc(c) != P2PHD_OK || c->N == 0) return 0;
+  return (c->dtype == P2PHD_BF16 && march_kind(c, 0) != 0 && march_w_ok(c)) ? 1 : 0;
+}
+
+extern "C" int p2phd_conv_fwd_lazy(const p2phd_conv_desc* c, const void* x_raw, const float* x_stats, int x_act, float x_eps,
+                                   const void* wp, const float* bias, void* y, float* stats, void* workspace, void* stream) {
+  if (int rc = check_desc(c)) return rc;
+  P2PHD_REQUIRE(p2phd_conv_lazy_ok(c), "conv_fwd_lazy: this layer cannot normalise its input on load (p2phd_conv_lazy_ok)");
+  P2PHD_REQUIRE(x_raw && x_stats && wp && y && (stats == nullptr || workspace), "conv_fwd_lazy: null pointer");
+  P2PHD_REQUIRE(x_act == P2PHD_ACT_NONE || x_act == P2PHD_ACT_RELU || x_act == P2PHD_ACT_LRELU, "conv_fwd_lazy: activation %d", x_act);
+  hipStream_t st = (hipStream_t)stream;
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, 0, plans, &m);
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const float slope = x_act == P2PHD_ACT_RELU ? 0.f : (x_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+  const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+  float* table = static_cast<float*>(workspace);
+  if (int rc = march_run(c, 0, x_raw, wf, bias, y, stats ? table : nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st, x_stats, slope, x_eps)) return rc;
+  if (stats == nullptr) return P2PHD_OK;
+  int slots = 0, ncls = 1, slot_rows = 0;
+  long npix_cls = 0;
+  march_plan(c, 0, &slots, &ncls, &slot_rows, &npix_cls, nullptr);
+  return launch_stats_merge(table, stats, c->N, slots, ncls, cpitch(c->K), c->K, npix_cls, slot_rows, st);
+}
+
+extern "C" int p2phd_conv_wgrad_lazy(const p2phd_conv_desc* c, const void* x_raw, const float* x_stats, int x_act, float x_eps,
+                                     const void* dy, float* dw, float* db, int accumulate, void* workspace, void* stream) {
+  if (int rc = check_desc(c)) return rc;
+  P2PHD_REQUIRE(p2phd_conv_lazy_ok(c), "conv_wgrad_lazy: this layer cannot normalise its input on load (p2phd_conv_lazy_ok)");
+  P2PHD_REQUIRE(x_raw && x_stats && dy && dw && workspace, "conv_wgrad_lazy: null pointer");
+  P2PHD_REQUIRE(x_act == P2PHD_ACT_NONE || x_act == P2PHD_ACT_RELU || x_act == P2PHD_ACT_LRELU, "conv_wgrad_lazy: activation %d", x_act);
+  hipStream_t st = (hipStream_t)stream;
+  int Ho, Wo;
+  out_size(c, &Ho, &Wo);
+  const float slope = x_act == P2PHD_ACT_RELU ? 0.f : (x_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+  if (int rc = march_w_run(c, x_raw, dy, dw, accumulate, x_stats, slope, x_eps, static_cast<float*>(workspace), st)) return rc;
+  if (db != nullptr) return launch_colsum(c->dtype, dy, (long)c->N * Ho * Wo, cpitch(c->K), c->K, db, accumulate, st);
+  return P2PHD_OK;
 }

@@ -94,8 +94,14 @@ int march_kind(const p2phd_conv_desc* c, int which);
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);
 void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* ncls, int* slot_rows, long* npix_cls, int* bs_tiles);
+// in_stats != nullptr (forward launches): `in` is the raw output of an InstanceNorm block, normalised + activated on load
 int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
-              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st);
+              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st,
+              const float* in_stats = nullptr, float in_slope = 1.f, float in_eps = 0.f);
+bool march_w_ok(const p2phd_conv_desc* c);
+size_t march_w_workspace_floats(const p2phd_conv_desc* c);
+int march_w_run(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, int accumulate, const float* x_stats, float x_slope,
+                float x_eps, float* slabs, hipStream_t st);
 // thinwgrad.hip: weight gradient of the layers with <= 4 channels on one side (bf16); kind 0 = not eligible
 int thin_wgrad_kind(const p2phd_conv_desc* c);
 size_t thin_wgrad_workspace_floats(const p2phd_conv_desc* c);

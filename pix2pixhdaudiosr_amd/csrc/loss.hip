@@ -182,6 +182,14 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
 
 __global__ void adam_tick_kernel(long long* step_dev) { *step_dev += 1; }
 
+// base[off .. off + len) = 0 for every (off, len) pair: one launch for all the small segments of a flat buffer
+__global__ __launch_bounds__(256) void zero_segments_kernel(float* __restrict__ base, const long long* __restrict__ seg, int n) {
+  const int s = blockIdx.x;
+  if (s >= n) return;
+  const long long off = seg[2 * s], len = seg[2 * s + 1];
+  for (long long i = threadIdx.x; i < len; i += 256) base[off + i] = 0.f;
+}
+
 }  // namespace
 
 extern "C" int p2phd_loss_fwd(int kind, int dtype, const void* a, const void* b, float target, int64_t P, int C,
@@ -242,4 +250,11 @@ extern "C" int p2phd_adam_step_dev(float* params, const float* grads, float* exp
   }
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step_dev));
   return p2phd::check_launch("adam_step_dev");
+}
+
+extern "C" int p2phd_zero_segments(float* base, const int64_t* seg_dev, int n, void* stream) {
+  if (n <= 0) return P2PHD_OK;
+  P2PHD_REQUIRE(base && seg_dev, "zero_segments: null pointer");
+  hipLaunchKernelGGL(zero_segments_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, base, reinterpret_cast<const long long*>(seg_dev), n);
+  return p2phd::check_launch("zero_segments");
 }

@@ -54,7 +54,43 @@ struct MarchArgs {
   const float* bs_stats;  // [N][CO][2] (mean, M2)
   float* bs_out;          // [N][strips * nseg][CO][2] or nullptr
   float bs_inv_hw, bs_eps, bs_slope;
+  // LAZY input (round 4): `in` is the RAW output of an InstanceNorm block; this kernel applies (x - mean) * rstd and the
+  // activation while it stages rows into LDS -- the values p2phd_instnorm_act_fwd would have written, bit for bit, without
+  // that pass over the plane.  in_stats [N][CI][2] (mean, M2) of the producer; zeros of the padding stay zeros.
+  const float* in_stats;
+  float in_inv_hw, in_eps, in_slope;
 };
+
+// (mean, rstd) of the lazily normalised operand's channels of sample n -> LDS table [C][2]
+__device__ __forceinline__ void lazy_table_fill(float* tab, const float* stats, int n, int Cc, float inv_hw, float eps, int tid) {
+  if (tid < Cc) {
+    const float2 ms = *reinterpret_cast<const float2*>(stats + 2 * ((size_t)n * Cc + tid));
+    tab[2 * tid] = ms.x;
+    tab[2 * tid + 1] = rsqrtf(fmaxf(ms.y * inv_hw, 0.f) + eps);
+  }
+}
+// one 16-byte chunk (channels c0 .. c0 + 7) normalised + activated exactly as in_act_fwd_kernel does (norm.hip): (y - mean) * rstd
+// in f32, then the activation, then ONE rounding to bf16; !ok -> zeros.  This is VALU work on every staged element, so it is
+// kept short: bf16 -> f32 is a shift / mask on the packed dword, subtraction and multiplication go out as packed f32 pairs
+// (v_pk_add_f32 / v_pk_mul_f32: same roundings as the scalar forms), ReLU is one max, the padding mask is applied to the four
+// result dwords.  Table: [C][2] = (mean, rstd) interleaved, i.e. one float4 = two channels.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ u32x4 lazy_norm8(u32x4 raw, const float* tab, int c0, float slope, bool ok) {
+  u32x4 o;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {                                   // dword h = channels c0 + 2 h, c0 + 2 h + 1
+    const f32x4 t = *reinterpret_cast<const f32x4*>(tab + 2 * (c0 + 2 * h));   // (mean0, rstd0, mean1, rstd1)
+    const unsigned w = raw[h];
+    f32x2 v = {__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+    v = (v - f32x2{t[0], t[2]}) * f32x2{t[1], t[3]};
+    if (slope == 0.f) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }                 // (uniform branch)
+    else { v[0] = v[0] > 0.f ? v[0] : slope * v[0]; v[1] = v[1] > 0.f ? v[1] : slope * v[1]; }
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const bf16x2 r = {(bf16_t)v[0], (bf16_t)v[1]};
+    o[h] = ok ? *reinterpret_cast<const unsigned*>(&r) : 0u;
+  }
+  return o;
+}
 
 // geometry of one (CI, CO, WS) instance of the stride-2 gather ("S") kernel
 template <int CI, int CO, int WS>
@@ -70,7 +106,8 @@ struct SGeom {
   static constexpr int RING = 5 * ROWB;
   static constexpr int SPXB = CO * 2 + 16;                  // staging pixel pitch
   static constexpr int STAGEB = WS * SPXB;
-  static constexpr int LDS = RING + 2 * STAGEB;
+  static constexpr int TABB = CI * 2 * 4;                   // (mean, rstd) of a lazily normalised input
+  static constexpr int LDS = RING + 2 * STAGEB + TABB;
   static constexpr int NCH = 2 * RW * CQ;                   // chunks of the two new rows of a step
   static constexpr int LPT = (NCH + kThreads - 1) / kThreads;
   static_assert(CI % 16 == 0 && CO % 16 == 0 && kWaves % NWN == 0 && (WS / 16) % NWM == 0, "march: wave grid");
@@ -104,7 +141,7 @@ __global__ void march_s_pack_kernel(const float* __restrict__ w, bf16_t* __restr
 }
 
 // out[n, ho, wo, k] = sum_{r,s,c} in[n, 2 ho + r - 1, 2 wo + s - 1, c] * W[k][c][r][s]   (zeros outside the image)
-template <int CI, int CO, int WS, bool BSUM>
+template <int CI, int CO, int WS, bool BSUM, bool LAZY>
 __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
   typedef SGeom<CI, CO, WS> G;
   constexpr int CQ = G::CQ, KSR = G::KSR, KS = G::KS, NWN = G::NWN, MBW = G::MBW, RW = G::RW, PXB = G::PXB, ROWB = G::ROWB;
@@ -147,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
   // the two new input rows of a step, as 16-byte chunks: chunk j = tid + 768 u -> (row rr, pixel x, channel chunk q)
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
   unsigned colB[LPT], lw[LPT];
-  int rr_of[LPT];
+  int rr_of[LPT], q_of[LPT];
 #pragma unroll
   for (int u = 0; u < LPT; ++u) {
     const int j = tid + kThreads * u;
@@ -155,9 +192,14 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
     const int x = rem / CQ, q = rem - x * CQ;
     const int wi = 2 * wo0 - 1 + x;
     const bool ok = j < NCH && wi >= 0 && wi < Win;
-    rr_of[u] = rr;
+    rr_of[u] = rr; q_of[u] = q;
     colB[u] = ok ? (unsigned)((wi * CI + 8 * q) * 2) : kOOB;
     lw[u] = (unsigned)(min(x, RW - 1) * PXB + q * 16);
+  }
+  float* in_tab = reinterpret_cast<float*>(smem + G::RING + 2 * STAGEB);
+  if constexpr (LAZY) {
+    lazy_table_fill(in_tab, a.in_stats, n, CI, a.in_inv_hw, a.in_eps, tid);
+    __syncthreads();
   }
   const unsigned sampleB = (unsigned)((size_t)n * Hin * Win * CI * 2);
   const unsigned rowpitchB = (unsigned)(Win * CI * 2);
@@ -176,7 +218,12 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
 #pragma unroll
     for (int u = 0; u < LPT; ++u) {
       const int slot = (a_first + rr_of[u] + 5) % 5;
-      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = ld[u];
+      u32x4 v = ld[u];
+      if constexpr (LAZY) {
+        const int hi = 2 * h_first - 1 + a_first + rr_of[u];
+        v = lazy_norm8(v, in_tab, 8 * q_of[u], a.in_slope, hi >= 0 && hi < Hin && colB[u] != kOOB);
+      }
+      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = v;
     }
   };
 
@@ -267,7 +314,7 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
         for (int b = 0; b < MBW; ++b)
 #pragma unroll
           for (int e = 0; e < 4; ++e) { const float dlt = v[b][e] - mb; q += dlt * dlt; }
-        const float f = 1.f / (float)(s + 1), d = mb - st_mean;
+        const float f = __builtin_amdgcn_rcpf((float)(s + 1)), d = mb - st_mean;
         st_mean += d * f;
         st_m2 += q + d * d * ((float)(4 * MBW * s) * f);
         st_n = (float)(4 * MBW * (s + 1));
@@ -348,7 +395,8 @@ struct UGeom {
   static constexpr int SPXB = CO * 2 + 16;
   static constexpr int STAGEB = 2 * (2 * WS) * SPXB;        // two output rows of 2 WS pixels
   static constexpr int TABB = CO * 2 * 4;                   // (mean, rstd) of the fused backward sums
-  static constexpr int LDS = RING + 2 * STAGEB + TABB;
+  static constexpr int TABI = CI * 2 * 4;                   // (mean, rstd) of a lazily normalised input
+  static constexpr int LDS = RING + 2 * STAGEB + TABB + TABI;
   static constexpr int NCH = RW * CQ;
   static constexpr int LPT = (NCH + kThreads - 1) / kThreads;
   static constexpr int FA = 4 * KN, FB = 5 * KN;            // resident B fragments of a role-A / role-B wave
@@ -385,7 +433,7 @@ __global__ void march_u_pack_kernel(const float* __restrict__ w, bf16_t* __restr
   *reinterpret_cast<uint4*>(wf + (size_t)idx * 8) = *reinterpret_cast<const uint4*>(v);
 }
 
-template <int CI, int CO, int WS, bool BSUM>
+template <int CI, int CO, int WS, bool BSUM, bool LAZY>
 __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
   typedef UGeom<CI, CO, WS> G;
   constexpr int CQ = G::CQ, KN = G::KN, NB = G::NB, MBW = G::MBW, RW = G::RW, PXB = G::PXB, ROWB = G::ROWB;
@@ -421,13 +469,20 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
   // the new input row of a step as 16-byte chunks
   const auto rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, 0, (int)a.in_bytes, 0x00020000);
   unsigned colB[LPT], lw[LPT];
+  int q_of[LPT];
 #pragma unroll
   for (int u = 0; u < LPT; ++u) {
     const int j = tid + kThreads * u;
     const int x = j / CQ, q = j - x * CQ;
     const int wi = wi0 + x;
+    q_of[u] = q;
     colB[u] = (j < NCH && wi < Win) ? (unsigned)((wi * CI + 8 * q) * 2) : kOOB;
     lw[u] = (unsigned)(min(x, RW - 1) * PXB + q * 16);
+  }
+  float* in_tab = reinterpret_cast<float*>(smem + G::RING + 2 * STAGEB + G::TABB);
+  if constexpr (LAZY) {
+    lazy_table_fill(in_tab, a.in_stats, n, CI, a.in_inv_hw, a.in_eps, tid);
+    __syncthreads();
   }
   const unsigned sampleB = (unsigned)((size_t)n * Hin * Win * CI * 2);
   const unsigned rowpitchB = (unsigned)(Win * CI * 2);
@@ -443,8 +498,11 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
   auto write_row = [&](int arel) {
     const int slot = arel % 3;
 #pragma unroll
-    for (int u = 0; u < LPT; ++u)
-      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = ld[u];
+    for (int u = 0; u < LPT; ++u) {
+      u32x4 v = ld[u];
+      if constexpr (LAZY) v = lazy_norm8(v, in_tab, 8 * q_of[u], a.in_slope, i_first + arel < Hin && colB[u] != kOOB);
+      if (tid + kThreads * u < NCH) *reinterpret_cast<u32x4*>(smem + slot * ROWB + lw[u]) = v;
+    }
   };
 
   constexpr int CPR = CO / 8;
@@ -515,7 +573,7 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float dlt = v[e] - mb; q += dlt * dlt; }
         const int k = MBW * s + b;
-        const float f = 1.f / (float)(k + 1), d = mb - st_mean[slot];
+        const float f = __builtin_amdgcn_rcpf((float)(k + 1)), d = mb - st_mean[slot];   // (v_rcp_f32: 1 ulp; an IEEE division is ten instructions, six times per step)
         st_mean[slot] += d * f;
         st_m2[slot] += q + d * d * ((float)(4 * k) * f);
         st_n[slot] = (float)(4 * (k + 1));
@@ -608,6 +666,192 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// "W" kernel: the weight gradient of both layers --
+//   dW[o][i][r][s] = sum_{n, a, b} T96[n, a, b, o] * T48[n, 2 a + r - 1, 2 b + s - 1, i]
+// with (T96, T48) = (dy, x) for Conv2d(48, 96, 3, s2, p1) and (x, dy) for ConvTranspose2d(96, 48, 3, s2, p1, op1); both master
+// tensors are [96-side][48-side][3][3].  GEMM view: M = 96 (o), N = 9 taps x 48 (i), reduction over the pixels of the small
+// plane.  The same march as the S kernel (5-row ring of T48, one T96 row per step, every byte fetched once); the whole 96 x 432
+// result lives in the accumulators of the 12 waves (6 row blocks x 2 halves of the 27 column blocks: 56 VGPRs), both operands
+// are read pixel-major out of LDS with the transposing ds_read_b64_tr_b16 (the reduction index of the MFMA is the pixel), and a
+// workgroup leaves ONE slab at the end of its march; march_w_reduce_kernel adds the slabs in index order (no atomics).
+// LAZY = 1 / 2: T48 / T96 is the raw output of an InstanceNorm block, normalised + activated while it is staged (MarchArgs).
+// ------------------------------------------------------------------------------------------------------------------------
+struct MarchWArgs {
+  const bf16_t* t96;      // [N, Hs, Ws, 96]
+  const bf16_t* t48;      // [N, 2 Hs, 2 Ws, 48]
+  float* slab;            // [workgroups][96][432]
+  int N, Hs, Ws, strips, nseg, seg_rows;
+  unsigned t96_bytes, t48_bytes;
+  const float* stats;     // lazily normalised operand: [N][C][2] of its producer
+  float inv_hw, eps, slope;
+};
+struct WGeom {
+  static constexpr int WS = 64, RW = 2 * WS + 1;
+  static constexpr int PX48 = 48 * 2 + 16, ROW48 = RW * PX48, RING = 5 * ROW48;
+  static constexpr int PX96 = 96 * 2 + 32, ROW96 = WS * PX96;
+  static constexpr int TABB = 96 * 2 * 4;
+  static constexpr int LDS = RING + 2 * ROW96 + TABB;
+  static constexpr int NCH48 = 2 * RW * 6, LPT = (NCH48 + kThreads - 1) / kThreads;
+  static constexpr int NBLK = 27, NBW = 14;                 // column blocks (tap x channel third) in all / per wave half
+  static_assert(ROW48 % 16 == 0 && ROW96 % 16 == 0 && WS * 12 == kThreads, "march(W): geometry");
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_pair(const char* p0, const char* p1) {
+  typedef __attribute__((address_space(3))) s16x4* lp;
+  bf16x8 v;
+  *reinterpret_cast<s16x4*>(&v) = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p0);
+  *(reinterpret_cast<s16x4*>(&v) + 1) = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)p1);
+  return v;
+}
+
+template <int LAZY>
+__global__ __launch_bounds__(kThreads) void march_w_kernel(const MarchWArgs a) {
+  typedef WGeom G;
+  constexpr int WS = G::WS, RW = G::RW, PX48 = G::PX48, ROW48 = G::ROW48, PX96 = G::PX96, ROW96 = G::ROW96, LPT = G::LPT, NCH48 = G::NCH48;
+  extern __shared__ float4 smem_raw[];
+  char* smem = reinterpret_cast<char*>(smem_raw);
+  char* buf96 = smem + G::RING;
+  float* tab = reinterpret_cast<float*>(smem + G::RING + 2 * ROW96);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = wave % 6, nh = wave / 6;
+  int wg = (int)blockIdx.x;
+  const int seg = wg % a.nseg; wg /= a.nseg;
+  const int strip = wg % a.strips;
+  const int n = wg / a.strips;
+  const int w0 = strip * WS, h_first = seg * a.seg_rows;
+  const int Hb = 2 * a.Hs, Wb = 2 * a.Ws;
+
+  if constexpr (LAZY != 0) {
+    lazy_table_fill(tab, a.stats, n, LAZY == 1 ? 48 : 96, a.inv_hw, a.eps, tid);
+    __syncthreads();
+  }
+  const auto rs48 = __builtin_amdgcn_make_buffer_rsrc((void*)a.t48, 0, (int)a.t48_bytes, 0x00020000);
+  const auto rs96 = __builtin_amdgcn_make_buffer_rsrc((void*)a.t96, 0, (int)a.t96_bytes, 0x00020000);
+  // T48: the two new rows of a step as 16-byte chunks (as march_s_kernel); T96: one row of 64 pixels = one chunk per thread
+  unsigned colB[LPT], lw[LPT];
+  int rr_of[LPT], q_of[LPT];
+#pragma unroll
+  for (int u = 0; u < LPT; ++u) {
+    const int j = tid + kThreads * u;
+    const int rr = j / (RW * 6), rem = j - rr * (RW * 6);
+    const int x = rem / 6, q = rem - x * 6;
+    const int wi = 2 * w0 - 1 + x;
+    rr_of[u] = rr; q_of[u] = q;
+    colB[u] = (j < NCH48 && wi >= 0 && wi < Wb) ? (unsigned)((wi * 48 + 8 * q) * 2) : kOOB;
+    lw[u] = (unsigned)(min(x, RW - 1) * PX48 + q * 16);
+  }
+  const unsigned sample48 = (unsigned)((size_t)n * Hb * Wb * 48 * 2), pitch48 = (unsigned)(Wb * 48 * 2);
+  const int px96 = tid / 12, q96 = tid - px96 * 12;
+  const unsigned base96 = (unsigned)((((size_t)n * a.Hs + h_first) * a.Ws + w0 + px96) * 96 * 2 + q96 * 16), pitch96 = (unsigned)(a.Ws * 96 * 2);
+  const unsigned lw96 = (unsigned)(px96 * PX96 + q96 * 16);
+  u32x4 ld48[LPT], ld96;
+  auto issue = [&](int a_first, int srow, bool both) {              // T48 abs rows a_first, a_first + 1; T96 row srow of this segment
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int hi = 2 * h_first - 1 + a_first + rr_of[u];
+      const bool ok = hi >= 0 && hi < Hb && colB[u] != kOOB;
+      ld48[u] = __builtin_amdgcn_raw_buffer_load_b128(rs48, (int)(ok ? sample48 + (unsigned)hi * pitch48 + colB[u] : kOOB), 0, 0);
+    }
+    if (both) ld96 = __builtin_amdgcn_raw_buffer_load_b128(rs96, (int)(base96 + (unsigned)srow * pitch96), 0, 0);
+  };
+  auto write = [&](int a_first, int srow, bool both) {
+#pragma unroll
+    for (int u = 0; u < LPT; ++u) {
+      const int slot = (a_first + rr_of[u] + 5) % 5;
+      u32x4 v = ld48[u];
+      if constexpr (LAZY == 1) {
+        const int hi = 2 * h_first - 1 + a_first + rr_of[u];
+        v = lazy_norm8(v, tab, 8 * q_of[u], a.slope, hi >= 0 && hi < Hb && colB[u] != kOOB);
+      }
+      if (tid + kThreads * u < NCH48) *reinterpret_cast<u32x4*>(smem + slot * ROW48 + lw[u]) = v;
+    }
+    if (both) {
+      u32x4 v = ld96;
+      if constexpr (LAZY == 2) v = lazy_norm8(v, tab, 8 * q96, a.slope, true);
+      *reinterpret_cast<u32x4*>(buf96 + (srow & 1) * ROW96 + lw96) = v;
+    }
+  };
+  issue(-1, 0, true); write(-1, 0, true);
+  issue(1, 0, false); write(1, 0, false);
+  __syncthreads();
+
+  // transposing reads: lane 4 q + p of 16-lane group g supplies the address of pixel row (4 g + q [+ 16]) at columns 4 p .. 4 p + 3
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const unsigned aA = (unsigned)((4 * g + q4) * PX96 + (16 * mb + 4 * p4) * 2);
+  const unsigned aB = (unsigned)(2 * (4 * g + q4) * PX48 + 4 * p4 * 2);
+  f32x4 acc[G::NBW];
+#pragma unroll
+  for (int i = 0; i < G::NBW; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = a.seg_rows;
+  int a0 = 0;
+  for (int s = 0; s < nsteps; ++s) {
+    if (s + 1 < nsteps) issue(2 * s + 3, s + 1, true);
+    const char* A = buf96 + (s & 1) * ROW96 + aA;
+    bf16x8 af[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) af[kk] = tr_pair(A + (32 * kk) * PX96, A + (32 * kk + 16) * PX96);
+    int sl[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { sl[r] = a0 + r; sl[r] = sl[r] >= 5 ? sl[r] - 5 : sl[r]; }
+    auto body = [&](auto half_tag) {
+      constexpr int NH = decltype(half_tag)::value;
+#pragma unroll
+      for (int i = 0; i < G::NBW; ++i) {
+        constexpr int dummy = 0; (void)dummy;
+        const int nbk = G::NBW * NH + i;                             // compile-time after unrolling
+        if (nbk < G::NBLK) {
+          const int t = nbk / 3, j = nbk - 3 * t, r = t / 3, s3 = t - 3 * r;
+          const char* B = smem + sl[r] * ROW48 + aB + s3 * PX48 + 32 * j;
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const bf16x8 bfr = tr_pair(B + 2 * (32 * kk) * PX48, B + 2 * (32 * kk + 16) * PX48);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[i], 0, 0, 0);
+          }
+        }
+      }
+    };
+    if (nh == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+    if (s + 1 < nsteps) write(2 * s + 3, s + 1, true);
+    __syncthreads();
+    a0 += 2;
+    a0 = a0 >= 5 ? a0 - 5 : a0;
+  }
+  // this workgroup's slab: lane (n16 = column within the block, g) holds rows 4 g + e of block i
+  float* sb = a.slab + (size_t)blockIdx.x * (96 * 432);
+  const int n16 = lane & 15;
+#pragma unroll
+  for (int i = 0; i < G::NBW; ++i) {
+    const int nbk = G::NBW * nh + i;
+    if (nbk < G::NBLK) {
+      const int col = (nbk / 3) * 48 + (nbk % 3) * 16 + n16;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sb[(16 * mb + 4 * g + e) * 432 + col] = acc[i][e];
+    }
+  }
+}
+
+// dw[o][i][r][s] (+)= sum_z slab[z][o][(3 r + s) * 48 + i], z in index order (fixed: reproducible)
+__global__ __launch_bounds__(256) void march_w_reduce_kernel(const float* __restrict__ slab, int nslabs, float* __restrict__ dw, int accumulate) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= 96 * 432) return;
+  float sum = 0.f;
+  for (int z0 = 0; z0 < nslabs; z0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)min(z0 + u, nslabs - 1) * (96 * 432) + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += z0 + u < nslabs ? v[u] : 0.f;
+  }
+  const int o = e / 432, col = e - o * 432, t = col / 48, i = col - t * 48;
+  float* d = dw + (size_t)o * 432 + i * 9 + t;
+  *d = accumulate ? *d + sum : sum;
+}
+
 // segments per strip: enough workgroups for two rounds of the CUs when the plane allows, rows per segment >= 4
 int pick_segments(int N, int strips, int Ho) {
   const int cus = g_opt_cus > 0 ? g_opt_cus : device_cus();
@@ -695,7 +939,8 @@ void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* ncls, int*
 }
 
 int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* wf, const float* bias, void* out, float* table,
-              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st) {
+              const void* bs_y, const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st,
+              const float* in_stats, float in_slope, float in_eps) {
   const int kind = march_kind(c, which);
   P2PHD_REQUIRE(kind == 1 || kind == 2, "march_run: layer has no marching kernel");
   const MarchGeom g = march_geom(c, kind, which);
@@ -709,14 +954,56 @@ int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* w
   a.in_bytes = (unsigned)ib;
   a.bs_y = (const bf16_t*)bs_y; a.bs_stats = bs_stats; a.bs_out = bs_out;
   a.bs_inv_hw = bs_inv_hw; a.bs_eps = bs_eps; a.bs_slope = bs_slope;
+  a.in_stats = in_stats; a.in_slope = in_slope; a.in_eps = in_eps; a.in_inv_hw = 1.f / ((float)a.Hin * (float)a.Win);
+  P2PHD_REQUIRE(in_stats == nullptr || bs_out == nullptr, "march_run: a lazily normalised input goes with forward launches");
   const dim3 grid((unsigned)(a.N * a.strips * a.nseg));
   auto launch = [&](auto kern, int lds, const char* what) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);
     return check_launch(what);
   };
-  if (kind == 1) return bs_out ? launch(march_s_kernel<48, 96, 64, true>, GS::LDS, "march_s") : launch(march_s_kernel<48, 96, 64, false>, GS::LDS, "march_s");
-  return bs_out ? launch(march_u_kernel<96, 48, 64, true>, GU::LDS, "march_u") : launch(march_u_kernel<96, 48, 64, false>, GU::LDS, "march_u");
+  if (kind == 1) {
+    if (in_stats) return launch(march_s_kernel<48, 96, 64, false, true>, GS::LDS, "march_s(lazy)");
+    return bs_out ? launch(march_s_kernel<48, 96, 64, true, false>, GS::LDS, "march_s") : launch(march_s_kernel<48, 96, 64, false, false>, GS::LDS, "march_s");
+  }
+  if (in_stats) return launch(march_u_kernel<96, 48, 64, false, true>, GU::LDS, "march_u(lazy)");
+  return bs_out ? launch(march_u_kernel<96, 48, 64, true, false>, GU::LDS, "march_u") : launch(march_u_kernel<96, 48, 64, false, false>, GU::LDS, "march_u");
+}
+
+// ---- weight gradient of both layers (march_w_kernel) --------------------------------------------------------------------
+bool march_w_ok(const p2phd_conv_desc* c) { return march_kind(c, 0) != 0; }   // same layers, same geometry rule as the forward
+
+size_t march_w_workspace_floats(const p2phd_conv_desc* c) {
+  if (!march_w_ok(c)) return 0;
+  const MarchGeom g = march_geom(c, 1, 0);
+  return (size_t)c->N * g.strips * g.nseg * 96 * 432;
+}
+
+// x / dy in the layer's own orientation; x_stats != nullptr: x is the RAW output of its producer's InstanceNorm block
+int march_w_run(const p2phd_conv_desc* c, const void* x, const void* dy, float* dw, int accumulate, const float* x_stats, float x_slope,
+                float x_eps, float* slabs, hipStream_t st) {
+  P2PHD_REQUIRE(march_w_ok(c), "march_w_run: layer has no marching weight-gradient kernel");
+  const bool conv = !c->transposed;
+  const MarchGeom g = march_geom(c, 1, 0);                        // Ho x Wo = the 96-channel plane, Hin x Win = the 48-channel plane
+  MarchWArgs a{};
+  a.t96 = (const bf16_t*)(conv ? dy : x); a.t48 = (const bf16_t*)(conv ? x : dy); a.slab = slabs;
+  a.N = c->N; a.Hs = g.Ho; a.Ws = g.Wo; a.strips = g.strips; a.nseg = g.nseg; a.seg_rows = g.seg_rows;
+  const size_t b96 = (size_t)a.N * a.Hs * a.Ws * 96 * 2, b48 = (size_t)a.N * 4 * a.Hs * a.Ws * 48 * 2;
+  P2PHD_REQUIRE(b96 < 0xFFFFFFF0ull && b48 < 0xFFFFFFF0ull, "march(W): tensor larger than 4 GiB");
+  a.t96_bytes = (unsigned)b96; a.t48_bytes = (unsigned)b48;
+  a.stats = x_stats; a.slope = x_slope; a.eps = x_eps;
+  a.inv_hw = conv ? 1.f / ((float)(2 * a.Hs) * (float)(2 * a.Ws)) : 1.f / ((float)a.Hs * (float)a.Ws);   // plane of x
+  const int wgs = a.N * a.strips * a.nseg;
+  auto launch = [&](auto kern) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WGeom::LDS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kThreads), WGeom::LDS, st, a);
+  };
+  if (x_stats == nullptr) launch(march_w_kernel<0>);
+  else if (conv) launch(march_w_kernel<1>);                       // x is the 48-channel operand
+  else launch(march_w_kernel<2>);
+  if (int rc = check_launch("march_w")) return rc;
+  hipLaunchKernelGGL(march_w_reduce_kernel, dim3((96 * 432 + 255) / 256), dim3(256), 0, st, slabs, wgs, dw, accumulate);
+  return check_launch("march_w_reduce");
 }
 
 }  // namespace p2phd

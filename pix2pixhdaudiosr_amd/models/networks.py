@@ -15,6 +15,8 @@ ResnetBlock, the deprecated Encoder / Vgg19 / VGGLoss leftovers of upstream pix2
 import functools
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -111,8 +113,8 @@ class _ConvStep:
         if _ops.kmajor_eligible(spec.cin, spec.cout, spec.k, spec.stride, spec.transposed):
             conv.weight._p2phd_kmajor = True
 
-    def run(self, x, residual=None, link=None, exclusive=False):
-        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link, exclusive)
+    def run(self, x, residual=None, link=None, exclusive=False, defer=False):
+        return conv_block(x, self.conv.weight, self.conv.bias, self.spec, residual, link, exclusive, defer)
 
 
 class _ResStep:
@@ -217,7 +219,14 @@ def _run(steps, x, residual_last=None, cuts=None, cut_after=(), first_exclusive=
     for j, s in enumerate(steps):
         # from the second step on, the input is the previous step's output and is consumed here only (a cut tensor is an
         # endpoint of torch.autograd.grad, not a consumer): the step may fuse the producer's backward sums (_ops)
-        x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0 or first_exclusive)
+        if isinstance(s, _ConvStep):
+            # the next step normalises on load (csrc/march.hip): this one hands out its raw output + statistics (_ops.LazyNorm)
+            nxt = steps[j + 1] if j + 1 < len(steps) else None
+            defer = (isinstance(nxt, _ConvStep) and s.spec.norm and x.dtype == torch.bfloat16 and _ops.lazy_static_ok(nxt.spec)
+                     and os.environ.get("P2PHD_LAZY", "1") != "0")
+            x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0 or first_exclusive, defer=defer)
+        else:
+            x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0 or first_exclusive)
         if cuts is not None and j in cut_after:
             cuts.append(x)
     return x

@@ -87,8 +87,16 @@ class FlatAdam(torch.optim.Optimizer):
         update) is zeroed then (`_flush_fresh`)."""
         self._install_grad_views()
         if lazy:
+            # weights (>= 2-D): overwritten by their first gradient; the small 1-D parameters (biases: several kernels ADD their
+            # column sums) are zeroed here, all in one launch
+            small = [(o, p.numel()) for p, o in zip(self._params, self._offs) if p.dim() < 2]
+            if small:
+                if getattr(self, "_small_seg", None) is None:
+                    self._small_seg = torch.tensor([v for pair in small for v in pair], dtype=torch.int64, device=self.flat_g.device)
+                _lib.check(_lib.lib().p2phd_zero_segments(_lib.ptr(self.flat_g), _lib.ptr(self._small_seg), len(small), _lib.stream_ptr()),
+                           "zero_segments")
             for p in self._params:
-                p._p2phd_fresh = True
+                p._p2phd_fresh = p.dim() >= 2
             self._lazy = True
             return
         self.flat_g.zero_()

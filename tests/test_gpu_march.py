@@ -64,3 +64,57 @@ def test_marching_input_gradient_equals_the_gather_gemm(geom):
     assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 4e-3                     # forward: the "U" kernel vs the merged sub-pixel launch
     for a, c in zip(g1[:2], g0[:2]):                                               # input gradient: the "S" kernel vs the stride-2 gather-GEMM
         assert rel_err(a.cpu().numpy(), c.cpu().numpy()) < 1.2e-2
+
+
+@pytest.mark.parametrize("kind", ["conv", "convT"])
+def test_lazily_normalised_input_equals_the_materialised_form(kind):
+    """Round 4: a block whose only consumer is a marching layer hands out its RAW conv output + statistics (`defer`), and that
+    layer's forward and weight gradient apply InstanceNorm + ReLU while staging rows (p2phd_conv_fwd_lazy / _wgrad_lazy): the
+    InstanceNorm forward pass over the plane is not run.  Outputs and every gradient must equal the materialised form BIT FOR
+    BIT (same kernels, same operand values)."""
+    from pix2pixhdaudiosr_amd import _ops
+    gen = torch.Generator().manual_seed(41)
+    if kind == "conv":            # c7-like producer 8 -> 48, then Conv2d(48, 96, 3, s2)
+        N, c0, H, W = 2, 8, 16, 128
+        specP = _ops.ConvSpec(c0, 48, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+        specL = _ops.ConvSpec(48, 96, 3, 2, 1, 0, False, 0, True, _ops.ACT_RELU)
+        w1 = torch.randn(48, c0, 3, 3, generator=gen) * 0.1
+        w2 = torch.randn(96, 48, 3, 3, generator=gen) * 0.05
+        cout = 96
+    else:                         # producer 16 -> 96, then ConvTranspose2d(96, 48, 3, s2)
+        N, c0, H, W = 2, 16, 8, 64
+        specP = _ops.ConvSpec(c0, 96, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+        specL = _ops.ConvSpec(96, 48, 3, 2, 1, 0, True, 1, True, _ops.ACT_RELU)
+        w1 = torch.randn(96, c0, 3, 3, generator=gen) * 0.1
+        w2 = torch.randn(96, 48, 3, 3, generator=gen) * 0.05
+        cout = 48
+    assert _ops.lazy_static_ok(specL)
+    x = torch.randn(N, c0, H, W, generator=gen)
+    b1 = torch.randn(specP.cout, generator=gen) * 0.1
+
+    def run(defer):
+        xd = x.cuda().requires_grad_(True)
+        w1d, w2d, b1d = w1.cuda().requires_grad_(True), w2.cuda().requires_grad_(True), b1.cuda().requires_grad_(True)
+        h = _ops.conv_block(_ops.ToPhysical.apply(torch.bfloat16, xd), w1d, b1d, specP, defer=defer)
+        assert (getattr(h, "_p2phd_lazy", None) is not None) == defer
+        o = _ops.conv_block(h, w2d, None, specL, exclusive=True)
+        out = _ops.FromPhysical.apply(o, cout)
+        cot = torch.randn(out.shape, generator=torch.Generator().manual_seed(6)).cuda()
+        g = torch.autograd.grad((out * cot).sum(), [xd, w1d, w2d])
+        torch.cuda.synchronize()
+        return out.detach(), g
+
+    o1, g1 = run(True)
+    o0, g0 = run(False)
+    assert torch.equal(o1, o0)
+    for a, b in zip(g1, g0):
+        assert torch.equal(a, b)
+    # a consumer that cannot normalise on load gets the materialised tensor (fp32 here: no marching kernels)
+    xd = x.cuda().requires_grad_(True)
+    h = _ops.conv_block(_ops.ToPhysical.apply(torch.float32, xd), w1.cuda(), b1.cuda(), specP, defer=True)
+    o = _ops.FromPhysical.apply(_ops.conv_block(h, w2.cuda(), None, specL), cout)
+    h2 = _ops.conv_block(_ops.ToPhysical.apply(torch.float32, xd), w1.cuda(), b1.cuda(), specP)
+    o2 = _ops.FromPhysical.apply(_ops.conv_block(h2, w2.cuda(), None, specL), cout)
+    assert torch.equal(o, o2)
+    with pytest.raises(Exception):
+        _ops.FromPhysical.apply(h, specP.cout)                      # a raw tensor must not leave the chain

@@ -46,6 +46,16 @@ def layer(name, cin, cout, transposed, H, W, which):
     nbytes = (x.numel() + y.numel()) * 2
     if which == "fwd":
         fn = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp0), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
+    elif which == "fwd_lazy":
+        fn = lambda: _ops.check(L.p2phd_conv_fwd_lazy(C.byref(d), _ops.ptr(x), _ops.ptr(prev_stats), _ops.ACT_RELU, 1e-5, _ops.ptr(wp0), None, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
+    elif which == "wgrad_lazy":
+        gw = torch.empty_like(w)
+        wsw = _ops.workspace(max(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), 1 << 20), "cuda", "w")
+        fn = lambda: _ops.check(L.p2phd_conv_wgrad_lazy(C.byref(d), _ops.ptr(x), _ops.ptr(prev_stats), _ops.ACT_RELU, 1e-5, _ops.ptr(dy), _ops.ptr(gw), None, 0, _ops.ptr(wsw), _ops.stream_ptr()))
+    elif which == "wgrad":
+        gw = torch.empty_like(w)
+        wsw = _ops.workspace(max(L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), 1 << 20), "cuda", "w")
+        fn = lambda: _ops.check(L.p2phd_conv_wgrad(C.byref(d), _ops.ptr(x), _ops.ptr(dy), _ops.ptr(gw), None, _ops.ptr(wsw), _ops.stream_ptr()))
     elif which == "dgrad":
         fn = lambda: _ops.check(L.p2phd_conv_dgrad(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), None, _ops.ptr(gx), _ops.ptr(ws), _ops.stream_ptr()))
     else:
@@ -53,11 +63,11 @@ def layer(name, cin, cout, transposed, H, W, which):
                                                         _ops.ACT_RELU, 1e-5, _ops.ptr(bst), _ops.ptr(ws), _ops.stream_ptr()))
     res = {0: [], 1: []}
     for rnd in range(3):
-        for march in (0, 1):
+        for march in ((1,) if "lazy" in which else (0, 1)):
             _ops.check(L.p2phd_set_option(b"march", march))
             res[march].append(timeit(fn))
     _ops.check(L.p2phd_set_option(b"march", 1))
-    g, m = min(res[0]), min(res[1])
+    g, m = min(res[0] or [float("nan")]), min(res[1])
     print(f"{name:34s} {which:10s} generic {g:7.1f} us ({nbytes / g / 1e6:4.2f} TB/s) | marching {m:7.1f} us ({nbytes / m / 1e6:4.2f} TB/s)   "
           f"all: {[round(v) for v in res[0]]} vs {[round(v) for v in res[1]]}", flush=True)
 
@@ -69,3 +79,9 @@ layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "dgrad+bsum")
 layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "fwd")
 layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "dgrad")
 layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "dgrad+bsum")
+layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "wgrad")
+layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "fwd_lazy")
+layer("G down 48->96 s2 @512x256", 48, 96, False, 512, 256, "wgrad_lazy")
+layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "fwd_lazy")
+layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "wgrad_lazy")
+layer("G up 96->48 convT @256x128", 96, 48, True, 256, 128, "wgrad")
