@@ -244,6 +244,8 @@ def main():
                          "count launches or bytes per step: tools/collect_step_traffic.sh)")
     ap.add_argument("--comm-cus", type=int, default=0,
                     help="data parallel: run the step on a stream whose CU mask leaves this many CUs to the RCCL kernels (0 = off)")
+    ap.add_argument("--wire-bf16", action="store_true",
+                    help="data parallel: the generator's gradient buckets travel as bf16 (half the xGMI bytes; fp32 accumulation in Adam)")
     ap.add_argument("--fp8", action="store_true",
                     help="variant of BASELINE configs[4]: e4m3 forward of the wide stride-1 convs on top of bf16 (NOT the headline dtype)")
     a = ap.parse_args()
@@ -299,7 +301,8 @@ def main():
     if rehearse:
         opt.grad_buckets = 4
     if dist_on:
-        parallel_state.enable_data_parallel(model, world, force_collectives=rehearse)
+        parallel_state.enable_data_parallel(model, world, force_collectives=rehearse,
+                                            wire_dtype=torch.bfloat16 if a.wire_bf16 else torch.float32)
     T = (FRAMES - 1) * opt.hop_length
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     hr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
@@ -381,8 +384,8 @@ def main():
         gb = [int(b - a) for a, b in model.optimizer_G.bucket_log]
         dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rehearsal_one_rank": rehearse,
                      "g_gradient_buckets": gb,
-                     "bucket_bytes": {"G": [4 * n for n in gb], "D": [4 * int(model.optimizer_D._total)]},
-                     "gradient_dtype_on_the_wire": "fp32",
+                     "bucket_bytes": {"G": [(2 if a.wire_bf16 else 4) * n for n in gb], "D": [4 * int(model.optimizer_D._total)]},
+                     "gradient_dtype_on_the_wire": {"G": "bf16" if a.wire_bf16 else "fp32", "D": "fp32"},
                      "exposed_exchange_ms": float(ex[0] + ex[1]), "exposed_exchange_ms_G": float(ex[0]),
                      "exposed_exchange_ms_D": float(ex[1]), "host_wait_ms": float(ex[2]),
                      "waits_per_step": (exch["G"]["waits"] + exch["D"]["waits"]) / a.steps,

@@ -25,7 +25,7 @@ def shard_batch(global_batch, rank, world_size):
     return rank * per, (rank + 1) * per
 
 
-def enable_data_parallel(model, world_size, process_group=None, broadcast=True, force_collectives=False):
+def enable_data_parallel(model, world_size, process_group=None, broadcast=True, force_collectives=False, wire_dtype=torch.float32):
     import torch.distributed as dist
     if broadcast:
         # start from rank 0's weights whatever the local seeds were
@@ -33,7 +33,9 @@ def enable_data_parallel(model, world_size, process_group=None, broadcast=True, 
             dist.broadcast(opt.flat_p, src=0, group=process_group)
         from . import _ops
         _ops.bump_weight_epoch()
-    model.optimizer_G.enable_data_parallel(world_size, process_group, force_collectives)
+    # (`wire_dtype` = torch.bfloat16: the generator's gradient buckets travel as bf16 -- 95 % of the exchanged bytes; the
+    # discriminator's 22 MB stay fp32)
+    model.optimizer_G.enable_data_parallel(world_size, process_group, force_collectives, wire_dtype)
     model.optimizer_D.enable_data_parallel(world_size, process_group, force_collectives)
     return model
 

@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def main():
-    out_dir, mode = sys.argv[1], sys.argv[2]                       # mode: graphed | eager
+    out_dir, mode = sys.argv[1], sys.argv[2]                       # mode: graphed | eager | graphed_wire_bf16
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
@@ -21,7 +21,7 @@ def main():
     from pix2pixhdaudiosr_amd import parallel_state as PS
     g = np.load(os.path.join(ROOT, "tests", "golden", "model_step.npz"))
     model = _model(g, mask=False)                                   # same initial weights on every rank, no mask noise
-    PS.enable_data_parallel(model, world)
+    PS.enable_data_parallel(model, world, wire_dtype=torch.bfloat16 if mode.endswith("wire_bf16") else torch.float32)
     gen = torch.Generator().manual_seed(77)
     B = 2 * world
     # every shard holds the same two clips (in a different order): the spectrogram normalisation uses the min / max of
@@ -33,7 +33,7 @@ def main():
     lr_all = torch.cat([lr0 if r % 2 == 0 else lr0.flip(0) for r in range(world)])
     a, b = PS.shard_batch(B, rank, world)
     hr, lr = hr_all[a:b].cuda(), lr_all[a:b].cuda()
-    step = model.train_step_graphed if mode == "graphed" else model.train_step
+    step = model.train_step_graphed if mode.startswith("graphed") else model.train_step
     losses, first = [], None
     for i in range(5):
         ld = step(lr, hr)

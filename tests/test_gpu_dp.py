@@ -13,20 +13,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(mode, out_dir):
-    port = 29600 + (os.getpid() + (7 if mode == "graphed" else 0)) % 300
+    port = 29600 + (os.getpid() + {"eager": 0, "graphed": 7, "graphed_wire_bf16": 13}[mode]) % 300
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "_dp_gpu_worker.py"), str(out_dir), mode]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-@pytest.mark.parametrize("mode", ["eager", "graphed"])
+@pytest.mark.parametrize("mode", ["eager", "graphed", "graphed_wire_bf16"])
 def test_two_ranks_one_gpu(tmp_path, mode):
+    """(`graphed_wire_bf16`, round 4: the generator's buckets travel as bf16 and are widened back into the fp32 gradient
+    buffer before Adam -- the replicas must still end bit-identical.)"""
     _run(mode, tmp_path)
     r0 = torch.load(tmp_path / f"{mode}_rank0.pt")
     r1 = torch.load(tmp_path / f"{mode}_rank1.pt")
     assert r0["steps"] == r1["steps"] == 5
-    assert r0["graphed"] == (mode == "graphed")
+    assert r0["graphed"] == mode.startswith("graphed")
     assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["D"], r1["D"])      # replicas stay bit-identical
     # bucketed exchange: the generator gradients left in 4 all-reduces, last layers first (the order the backward
     # produces them), contiguous, non-overlapping, covering the whole flat buffer; D in one
