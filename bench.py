@@ -30,7 +30,10 @@ M_G = 61.03e9                     # conv MACs / sample, GlobalGenerator ngf48 nd
 M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator num_D 2 @512x256
 
 
-def make_opt(batch, dtype_bf16=True, fp8=False):
+HALF = torch.bfloat16              # --fp16-storage: torch.float16 (the fp16 build of the library serves every launch)
+
+
+def make_opt(batch, dtype_bf16=True, fp8=False, fp16_storage=False):
     return SimpleNamespace(
         gpu_ids=[0], isTrain=True, checkpoints_dir="/tmp/p2phd_bench", name="bench", model="pix2pixHD",
         input_nc=2, output_nc=2, label_nc=0, hr_sampling_rate=48000, lr_sampling_rate=8000,
@@ -40,7 +43,7 @@ def make_opt(batch, dtype_bf16=True, fp8=False):
         use_hifigan_D=False, use_time_D=False, verbose=False, continue_train=False, load_pretrain="",
         which_epoch="latest", pool_size=0, lr=0.0002, beta1=0.5, no_vgg_loss=True, use_match_loss=False,
         niter_fix_global=0, explicit_encoding=True, alpha=0.6, min_value=1e-7, mask=True, mask_mode="mode2",
-        lambda_feat=10.0, fp16=dtype_bf16, fp8=fp8, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
+        lambda_feat=10.0, fp16=dtype_bf16, fp16_storage=fp16_storage, fp8=fp8, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
 
 
 def time_trunk_conv(batch, iters=20):
@@ -49,13 +52,13 @@ def time_trunk_conv(batch, iters=20):
     from pix2pixhdaudiosr_amd import _ops
     import ctypes as C
     spec = _ops.ConvSpec(768, 768, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
-    x = torch.randn(batch, 32, 16, 768, device="cuda").to(torch.bfloat16)
+    x = torch.randn(batch, 32, 16, 768, device="cuda").to(HALF)
     w = (torch.randn(768, 768, 3, 3, device="cuda") * 0.02)
-    d = spec.desc(batch, 32, 16, torch.bfloat16)
+    d = spec.desc(batch, 32, 16, HALF)
     wp = spec.packed(w, 0, d)
     y = torch.empty_like(x)
     stats = torch.zeros(batch, 768, 2, device="cuda")
-    L = _ops.lib()
+    L = _ops.lib_for(HALF)
     ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
                                                _ops.ptr(ws), _ops.stream_ptr()))
@@ -246,6 +249,9 @@ def main():
                     help="data parallel: run the step on a stream whose CU mask leaves this many CUs to the RCCL kernels (0 = off)")
     ap.add_argument("--wire-bf16", action="store_true",
                     help="data parallel: the generator's gradient buckets travel as bf16 (half the xGMI bytes; fp32 accumulation in Adam)")
+    ap.add_argument("--fp16-storage", action="store_true",
+                    help="variant: IEEE fp16 activations (the reference's autocast type) through libp2phd_hip_f16.so with the device "
+                         "loss scaler; same kernels, same byte counts (NOT the headline dtype: BASELINE configs[1] says bf16)")
     ap.add_argument("--fp8", action="store_true",
                     help="variant of BASELINE configs[4]: e4m3 forward of the wide stride-1 convs on top of bf16 (NOT the headline dtype)")
     a = ap.parse_args()
@@ -294,7 +300,12 @@ def main():
     from pix2pixhdaudiosr_amd import parallel_state
 
     torch.manual_seed(1234)                      # same initial weights on every rank (reference default seed)
-    opt = make_opt(a.batch, fp8=a.fp8)
+    if a.fp16_storage:
+        global HALF
+        HALF = torch.float16
+        if a.fp8:
+            raise SystemExit("--fp8 rides on bf16; not with --fp16-storage")
+    opt = make_opt(a.batch, fp8=a.fp8, fp16_storage=a.fp16_storage)
     opt.gpu_ids = [local]
     opt.comm_cus = a.comm_cus
     model = create_model(opt)
@@ -403,7 +414,7 @@ def main():
             "metric": "MDCT spectrogram frames/sec (G+D fwd+bwd) at 512x256",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16+fp8(e4m3 forward of the wide convs)" if a.fp8 else "bf16", "data": "synthetic",
+            "dtype": "bf16+fp8(e4m3 forward of the wide convs)" if a.fp8 else ("fp16" if a.fp16_storage else "bf16"), "data": "synthetic",
             "config": {"workload": "configs[1]: ngf=48 n_local_enhancers=0 (GlobalGenerator nd4 nb9) + MultiscaleDiscriminator "
                                    "num_D=2, 512x256 MDCT4 (n_fft 1024, hop 512), LSGAN + feature matching, Adam, bf16 MFMA",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
@@ -414,6 +425,12 @@ def main():
                                            "D(fake) forward executes ~3.5 % fewer"},
             "per_rank_ms_per_step": rank_ms,
         }
+        if a.fp16_storage:
+            out["fp16_storage"] = {"library": "libp2phd_hip_f16.so (the same sources with the 16-bit type = _Float16)",
+                                   "loss_scale_after_the_run": model.scaler.get_scale(),
+                                   "updates_applied": {"G": model.optimizer_G.steps_taken(), "D": model.optimizer_D.steps_taken()},
+                                   "what": "the reference's AMP storage type (train.py:62-67) with optim.DeviceGradScaler inside the captured step; "
+                                           "fp32 master weights and fp32 MFMA accumulation as in bf16"}
         if a.fp8:
             from pix2pixhdaudiosr_amd import _ops as _o
             out["fp8"] = {"layers_switched": model.fp8_layers, "fp8_conv_launches_recorded_by_the_host": _o._FP8_CALLS[0],
@@ -452,7 +469,7 @@ def main():
         sec_dgrad = None
         if world == 1 and not a.no_probes:                         # extra steps on one rank only would desynchronise the collectives
             import ctypes as C
-            L = _ops.lib()
+            L = _ops.lib_for(HALF)
 
             def probe(pad_mode, esize):
                 # events around the gconv launches of the trunk layer only (cin pitch 768, GEMM-K 9 * 768, 32 x 16 grid), on

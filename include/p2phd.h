@@ -40,9 +40,13 @@ extern "C" {
 #define P2PHD_ELAUNCH      -2   /* HIP launch error */
 #define P2PHD_EUNSUPPORTED -3   /* valid request this build does not implement */
 
-/* element types of activation / weight buffers */
+/* element types of activation / weight buffers.  P2PHD_BF16 names THE LIBRARY'S 16-BIT STORAGE TYPE: bf16 in libp2phd_hip.so
+ * (the benchmarked mode), IEEE fp16 in libp2phd_hip_f16.so -- the same sources built with -DP2PHD_F16 (the reference's actual AMP
+ * type: train.py:62-67 runs torch.cuda.amp.autocast, i.e. fp16 activations with fp32 accumulation and a GradScaler).  Same entry
+ * points, same layouts; p2phd_half_type() returns 1 (bf16) or 2 (fp16). */
 #define P2PHD_F32  0
 #define P2PHD_BF16 1
+int p2phd_half_type(void);
 
 const char* p2phd_last_error(void);
 int p2phd_abi_version(void);
@@ -308,6 +312,17 @@ int p2phd_conv_fwd_lazy(const p2phd_conv_desc* c, const void* x_raw, const float
                         const void* packed_fwd, const float* bias, void* y, float* stats, void* workspace, void* stream);
 int p2phd_conv_wgrad_lazy(const p2phd_conv_desc* c, const void* x_raw, const float* x_stats, int x_act, float x_eps,
                           const void* dy, float* dw, float* db, int accumulate, void* workspace, void* stream);
+
+/* Loss scaling for fp16 storage (torch.cuda.amp.GradScaler of train.py:62-67,165-181, device-resident so that a captured step
+ * replays): scaler_state = 8 floats in device memory: [0] scale, [1] 1 / scale, [2] growth tracker, [3], [4] non-finite flags of
+ * two gradient buffers (generator, discriminator).  The caller multiplies the loss by state[0] before its backward pass;
+ * p2phd_adam_step_scaled = p2phd_adam_step_dev that first scans `grads` for inf / nan (flag 3 + found_index), unscales by
+ * state[1] and SKIPS the update (and the step count) when the flag is set; p2phd_scaler_update = GradScaler.update(): backoff on
+ * a flag, growth after growth_interval clean steps, flags cleared. */
+int p2phd_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                           int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, float* scaler_state,
+                           int found_index, void* stream);
+int p2phd_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 /* base[off, off + len) = 0 for n (off, len) pairs of int64 in DEVICE memory: one launch for the small segments of a flat
  * gradient buffer (the bias gradients, which several kernels add into; the weight gradients are overwritten by their first

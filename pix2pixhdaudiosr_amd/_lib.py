@@ -12,6 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # P2PHD_LIB: load another build of the same ABI (kernel A/B and ablation experiments, tools/ablate_gconv.py)
 LIB_PATH = os.environ.get("P2PHD_LIB") or os.path.join(_HERE, "libp2phd_hip.so")
+# the same sources with IEEE fp16 as the 16-bit storage type (csrc/common.h; opt.fp16_storage / compute dtype torch.float16)
+LIB_PATH_F16 = os.path.join(_HERE, "libp2phd_hip_f16.so")
 
 F32, BF16 = 0, 1
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
@@ -23,6 +25,7 @@ SIGNATURES = {
     "p2phd_device_info": (_i32, [C.c_char_p, _i32]),
     "p2phd_set_option": (_i32, [C.c_char_p, _i32]),
     "p2phd_reduction_reset": (_i32, [_vp]),
+    "p2phd_half_type": (_i32, []),
     "p2phd_probe_gconv": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_gconv_ex": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_read": (_i32, [_vp, _i32]),
@@ -80,6 +83,8 @@ SIGNATURES = {
     "p2phd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _i64, _f32, _vp]),
     "p2phd_adam_step_dev": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp]),
     "p2phd_zero_segments": (_i32, [_vp, _vp, _i32, _vp]),
+    "p2phd_adam_step_scaled": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i32, _vp]),
+    "p2phd_scaler_update": (_i32, [_vp, _f32, _f32, _i32, _vp]),
     "p2phd_spectro_partials_floats": (_i64, [_i64, _i64, _i64]),
     "p2phd_spectro_encode": (_i32, [_vp, _i64, _i64, _i64, _f32, _f32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "p2phd_spectro_encode_ex": (_i32, [_vp, _i64, _i64, _i64, _i32, _f32, _f32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -102,39 +107,57 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "C", "H", "W", "K", "R", "S", "stride", "pad", "pad_mode",
                                          "transposed", "opad", "dtype", "w_layout")]
 
-_lib = None
+_libs = {}
+_last = [None]            # the library the latest call went to (p2phd_last_error is per library)
 
 
 class P2PHDError(RuntimeError):
     pass
 
 
-def lib():
-    """The loaded library; raises (never falls back) when it has not been built."""
-    global _lib
-    if _lib is None:
-        if not os.path.isfile(LIB_PATH):
-            raise ImportError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built "
-                "(run `make -C pix2pixhdaudiosr_amd/csrc` or `__graft_entry__.build()`); "
-                "this package has no CPU fallback")
-        l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
-        # P2PHD_OPTIONS="name=value,...": tuning overrides of p2phd_set_option for A/B runs of whole programs (bench.py, tools)
-        for item in filter(None, os.environ.get("P2PHD_OPTIONS", "").split(",")):
-            name, _, value = item.partition("=")
-            if l.p2phd_set_option(name.strip().encode(), int(value)) != 0:
-                raise P2PHDError(f"P2PHD_OPTIONS: {l.p2phd_last_error().decode()}")
-    return _lib
+def _load(path, want_half):
+    if not os.path.isfile(path):
+        raise ImportError(
+            f"{path} is missing: the HIP extension has not been built "
+            "(run `make -C pix2pixhdaudiosr_amd/csrc` or `__graft_entry__.build()`); "
+            "this package has no CPU fallback")
+    l = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    if l.p2phd_half_type() != want_half:
+        raise P2PHDError(f"{path}: 16-bit storage type {l.p2phd_half_type()} (1 bf16, 2 fp16), expected {want_half}")
+    # P2PHD_OPTIONS="name=value,...": tuning overrides of p2phd_set_option for A/B runs of whole programs (bench.py, tools)
+    for item in filter(None, os.environ.get("P2PHD_OPTIONS", "").split(",")):
+        name, _, value = item.partition("=")
+        if l.p2phd_set_option(name.strip().encode(), int(value)) != 0:
+            raise P2PHDError(f"P2PHD_OPTIONS: {l.p2phd_last_error().decode()}")
+    return l
+
+
+def lib(kind="bf16"):
+    """The loaded library (`kind`: 'bf16' = libp2phd_hip.so, 'f16' = libp2phd_hip_f16.so); raises (never falls back) when it has
+    not been built."""
+    l = _libs.get(kind)
+    if l is None:
+        l = _libs[kind] = _load(LIB_PATH if kind == "bf16" else LIB_PATH_F16, 1 if kind == "bf16" else 2)
+    _last[0] = l
+    return l
+
+
+def lib_for(dtype):
+    """The library whose 16-bit storage type is `dtype` (float32 tensors: the default library -- both hold the same f32 kernels)."""
+    return lib("f16" if dtype == torch.float16 else "bf16")
+
+
+def loaded():
+    return list(_libs.values())
 
 
 def check(rc, what=""):
     if rc != 0:
-        msg = lib().p2phd_last_error().decode("utf-8", "replace")
+        msg = (_last[0] or lib()).p2phd_last_error().decode("utf-8", "replace")
         raise P2PHDError(f"{what or 'p2phd'} failed (code {rc}): {msg}")
 
 

@@ -1,7 +1,7 @@
 """Host-side glue between torch tensors and the conv-stack entry points of libp2phd_hip.so.
 
 Internal activation format ("physical" tensors): contiguous NHWC ``[N, H, W, Cp]`` in the compute dtype
-(torch.bfloat16 or torch.float32), Cp = channels rounded up to 8 with zero pad channels.  Everything here
+(torch.bfloat16 / torch.float16 or torch.float32), Cp = channels rounded up to 8 with zero pad channels.  Everything here
 is plumbing: allocation through torch's caching allocator, pointers and the current stream handed to the
 C ABI, and ``torch.autograd.Function`` wrappers whose backward calls the HIP backward kernels.
 """
@@ -12,12 +12,14 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, check, lib, ptr, stream_ptr
+from ._lib import ConvDesc, check, lib, lib_for, ptr, stream_ptr
 
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+HALF_DTYPES = (torch.bfloat16, torch.float16)      # the 16-bit storage types (one library each)
 IN_EPS = 1e-5                      # nn.InstanceNorm2d default, models/networks.py:22
 
-_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+# (float16: the fp16 build of the library, where the ABI's 16-bit dtype code names IEEE half: _lib.lib_for)
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16, torch.float16: _lib.BF16}
 
 # bumped whenever master weights change behind torch's back (fused Adam, load_state_dict...)
 _WEIGHT_EPOCH = [0]
@@ -50,7 +52,9 @@ def begin_step(device, nbytes=32 << 20):
         a = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=device), "off": 0, "live": False}
         _ARENA[device] = a
     a["buf"].zero_()
-    check(lib().p2phd_reduction_reset(stream_ptr()), "reduction_reset")      # tickets of the fixed-order reductions: re-armed per step
+    lib()
+    for l_ in _lib.loaded():                                       # tickets of the fixed-order reductions: re-armed per step
+        check(l_.p2phd_reduction_reset(stream_ptr()), "reduction_reset")
     a["off"], a["live"] = 0, True
     a["gen"] = a.get("gen", 0) + 1
 
@@ -257,7 +261,7 @@ def dt_code(dtype):
     try:
         return _DT[dtype]
     except KeyError:
-        raise _lib.P2PHDError(f"compute dtype must be torch.float32 or torch.bfloat16, got {dtype}")
+        raise _lib.P2PHDError(f"compute dtype must be torch.float32, torch.bfloat16 or torch.float16, got {dtype}")
 
 
 _WS = {}
@@ -302,7 +306,7 @@ def cat_to_physical(xs, dtype, out=None):
         out = empty((N, H, W, cpitch(sum(chans))), dtype, xs[0].device)
     srcs = (C.c_void_p * len(xs))(*[x.data_ptr() for x in xs])
     cc = (C.c_int32 * len(xs))(*chans)
-    check(lib().p2phd_nchw_cat_to_nhwc(dt_code(out.dtype), srcs, cc, len(xs), ptr(out), N, H * W, out.shape[-1], stream_ptr()),
+    check(lib_for(out.dtype).p2phd_nchw_cat_to_nhwc(dt_code(out.dtype), srcs, cc, len(xs), ptr(out), N, H * W, out.shape[-1], stream_ptr()),
           "nchw_cat_to_nhwc")
     return out
 
@@ -315,7 +319,7 @@ def to_physical(x_nchw, dtype):
 def from_physical(x_phys, channels, ch_off=0):
     N, H, W, Cp = x_phys.shape
     out = empty((N, channels, H, W), torch.float32, x_phys.device)
-    check(lib().p2phd_nhwc_to_nchw(dt_code(x_phys.dtype), ptr(x_phys), ptr(out), N, channels, H * W, Cp, ch_off, stream_ptr()),
+    check(lib_for(x_phys.dtype).p2phd_nhwc_to_nchw(dt_code(x_phys.dtype), ptr(x_phys), ptr(out), N, channels, H * W, Cp, ch_off, stream_ptr()),
           "nhwc_to_nchw")
     return out
 
@@ -408,43 +412,45 @@ class ConvSpec:
 
     def fp8_ok(self, N, H, W):
         d = self.desc(N, H, W, torch.bfloat16)
-        return bool(lib().p2phd_conv_fp8_eligible(C.byref(d)))
+        return bool(lib_for(d.torch_dtype).p2phd_conv_fp8_eligible(C.byref(d)))
 
     def packed_fp8(self, weight, d):
         """e4m3 weights + per-layer scale (found on the device); re-quantised when the master copy changed."""
-        key = ("fp8", d.dtype)
+        key = ("fp8", d.torch_dtype)
         stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
-        nbytes = lib().p2phd_conv_fp8_packed_bytes(C.byref(d))
+        nbytes = lib_for(d.torch_dtype).p2phd_conv_fp8_packed_bytes(C.byref(d))
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
         w = _master_weight(weight, d)
-        check(lib().p2phd_conv_fp8_pack_weights(C.byref(d), ptr(w), ptr(buf), stream_ptr()), "conv_fp8_pack_weights")
+        check(lib_for(d.torch_dtype).p2phd_conv_fp8_pack_weights(C.byref(d), ptr(w), ptr(buf), stream_ptr()), "conv_fp8_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
 
     def desc(self, N, H, W, dtype, layout=0):
-        return ConvDesc(N, self.cin, H, W, self.cout, self.k, self.k, self.stride, self.pad, self.pad_mode,
-                        int(self.transposed), self.opad, dt_code(dtype), int(layout))
+        d = ConvDesc(N, self.cin, H, W, self.cout, self.k, self.k, self.stride, self.pad, self.pad_mode,
+                     int(self.transposed), self.opad, dt_code(dtype), int(layout))
+        d.torch_dtype = dtype                                      # (which library serves it: _lib.lib_for)
+        return d
 
     def out_size(self, d):
         ho, wo = C.c_int32(), C.c_int32()
-        check(lib().p2phd_conv_out_size(C.byref(d), C.byref(ho), C.byref(wo)), "conv_out_size")
+        check(lib_for(d.torch_dtype).p2phd_conv_out_size(C.byref(d), C.byref(ho), C.byref(wo)), "conv_out_size")
         return ho.value, wo.value
 
     def packed(self, weight, which, d):
         """Packed weights for forward (0) / input gradient (1); re-packed when the master copy changed.
         The dgrad pack of a stride-1 reflect conv depends on H, W only through the descriptor checks."""
-        key = (which, d.dtype)
+        key = (which, d.torch_dtype)
         stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
-        nbytes = lib().p2phd_conv_packed_bytes(C.byref(d), which)
+        nbytes = lib_for(d.torch_dtype).p2phd_conv_packed_bytes(C.byref(d), which)
         buf = hit[1] if hit is not None and hit[1].numel() == nbytes else empty((nbytes,), torch.uint8, weight.device)
         w = _master_weight(weight, d)
-        check(lib().p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
+        check(lib_for(d.torch_dtype).p2phd_conv_pack_weights(C.byref(d), which, ptr(w), ptr(buf), stream_ptr()), "conv_pack_weights")
         self._packed[key] = (stamp, buf)
         return buf
 
@@ -511,7 +517,7 @@ def materialise(x):
         return x
     N, H, W, _ = x.shape
     out = empty_like(x)
-    check(lib().p2phd_instnorm_act_fwd(dt_code(x.dtype), ptr(x), ptr(lz.stats), None, ptr(out), N, H * W, lz.channels, IN_EPS,
+    check(lib_for(x.dtype).p2phd_instnorm_act_fwd(dt_code(x.dtype), ptr(x), ptr(lz.stats), None, ptr(out), N, H * W, lz.channels, IN_EPS,
                                        lz.act, stream_ptr()), "instnorm_act_fwd")
     return out
 
@@ -530,10 +536,10 @@ class ConvBlockFn(torch.autograd.Function):
             raise _lib.P2PHDError(f"conv: input has channel pitch {Cp_in}, layer expects {cpitch(spec.cin)} ({spec.cin} channels)")
         d = spec.desc(N, H, W, x.dtype, w_layout(weight))
         Ho, Wo = spec.out_size(d)
-        L = lib()
+        L = lib_for(x.dtype)
         Cp_out = cpitch(spec.cout)
         lazy_in = getattr(x, "_p2phd_lazy", None)
-        if lazy_in is not None and not (x.dtype == torch.bfloat16 and (spec.norm or spec.act == ACT_NONE) and L.p2phd_conv_lazy_ok(C.byref(d))):
+        if lazy_in is not None and not (x.dtype in HALF_DTYPES and (spec.norm or spec.act == ACT_NONE) and L.p2phd_conv_lazy_ok(C.byref(d))):
             x, lazy_in = materialise(x), None                      # this layer cannot normalise on load after all
         x8 = getattr(x, "_p2phd_q8", None) if (spec.fp8 and x.dtype == torch.bfloat16) else None
         wp = spec.packed_fp8(weight, d) if x8 is not None else spec.packed(weight, 0, d)
@@ -593,8 +599,8 @@ class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         spec, d = ctx.spec, ctx.d
-        L = lib()
         x, y, stats, weight = ctx.x, ctx.y, ctx.stats, ctx.weight
+        L = lib_for(y.dtype)
         _check_arena(ctx, y.device)
         g = g.contiguous()
         if g.dtype != y.dtype:
@@ -845,7 +851,7 @@ class AvgPoolFn(torch.autograd.Function):
         N, H, W, Cp = x.shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         y = empty((N, Ho, Wo, Cp), x.dtype, x.device)
-        check(lib().p2phd_avgpool3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), N, H, W, channels, stream_ptr()), "avgpool_fwd")
+        check(lib_for(x.dtype).p2phd_avgpool3s2_fwd(dt_code(x.dtype), ptr(x), ptr(y), N, H, W, channels, stream_ptr()), "avgpool_fwd")
         ctx.meta = (N, H, W, Cp, channels)
         ctx.pair = _is_pair(x)
         return y
@@ -858,9 +864,9 @@ class AvgPoolFn(torch.autograd.Function):
         rng = _bwd_range(N, ctx.pair)
         if rng is not None:                                        # sample-range backward (backward_on_samples)
             lo, hi = rng
-            check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
+            check(lib_for(g.dtype).p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
         else:
-            check(lib().p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
+            check(lib_for(g.dtype).p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")
         link = ctx.link
         if (link is not None and not link.taken and link.g is None and link.conv_spec is not None
                 and id(link.conv_spec) not in _BWD_SKIP_DGRAD_SPECS):
@@ -896,7 +902,7 @@ class LossFn(torch.autograd.Function):
         # `into` (LossAcc): the kernel ADDS its term to that accumulator (it always accumulates: a fresh slot is zero), and
         # the tensor returned is only this term's handle in the autograd graph (LossSum wires the gradients)
         out = zeros((), a.device) if into is None else into
-        check(lib().p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(av), ptr(b), float(target), P, channels, float(coeff),
+        check(lib_for(a.dtype).p2phd_loss_fwd(kind, dt_code(a.dtype), ptr(av), ptr(b), float(target), P, channels, float(coeff),
                                    ptr(out), stream_ptr()), "loss_fwd")
         ctx.meta = (kind, float(target), float(coeff), channels, P, rows)
         ctx.a, ctx.b = a, b
@@ -915,7 +921,7 @@ class LossFn(torch.autograd.Function):
             da_full = torch.zeros_like(a)                          # (last-stage features: a few hundred KB)
             da = da_full[rows[0]:rows[1]]
         g = g.contiguous().float()
-        check(lib().p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(av), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
+        check(lib_for(a.dtype).p2phd_loss_bwd(kind, dt_code(a.dtype), ptr(av), ptr(b), target, P, channels, coeff, ptr(g), ptr(da),
                                    stream_ptr()), "loss_bwd")
         if _BWD_TRACE[0] is not None:
             _BWD_TRACE[0].append((("loss", kind, tuple(av.shape), coeff), g.detach().clone(), da.detach().clone(),

@@ -17,8 +17,8 @@
 
 namespace {
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 constexpr int TH = 8, TW = 128;            // output tile
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void c7_in_fwd_kernel(const bf16_t* __restrict
       const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(f[st & 1]);
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb)
-        acc[mb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[nb][s], bfr, acc[mb][nb], 0, 0, 0);
+        acc[mb][nb] = p2phd_mfma_16x16x32(wa[nb][s], bfr, acc[mb][nb]);
     }
     // epilogue of the group: bias, statistics, bf16, stage [pixel][channel]
 #pragma unroll
@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void c7_out_dgrad_fix_kernel(const bf16_t* __r
       for (int dh = dh_lo; dh <= dh_hi; ++dh)
         for (int dw = dw_lo; dw <= dw_hi; ++dw) {
           const unsigned d2 = *reinterpret_cast<const unsigned*>(dyn + ((size_t)(ph[a] - dh) * W + (pw[b] - dw)) * 8);
-          const float d0 = __uint_as_float(d2 << 16), d1 = __uint_as_float(d2 & 0xFFFF0000u);
+          float d0, d1;
+          p2phd_unpack2(d2, d0, d1);
           const float* w0 = s_w + ((dh * 7 + dw) * 2) * C + pc * 8;
           const float4 a0 = *reinterpret_cast<const float4*>(w0), a1 = *reinterpret_cast<const float4*>(w0 + 4);
           const float4 b0 = *reinterpret_cast<const float4*>(w0 + C), b1 = *reinterpret_cast<const float4*>(w0 + C + 4);
@@ -402,8 +403,8 @@ __global__ __launch_bounds__(256) void c7_out_fwd_kernel(const bf16_t* __restric
       const int offB = kc < 7 * C ? ((qwB + p) * C + kc) * 2 : ROWB;
       const bf16x8 fa = *reinterpret_cast<const bf16x8*>(xr + offA);
       const bf16x8 fb = *reinterpret_cast<const bf16x8*>(xr + offB);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], fa, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s], fb, acc[1], 0, 0, 0);
+      acc[0] = p2phd_mfma_16x16x32(wa[s], fa, acc[0]);
+      acc[1] = p2phd_mfma_16x16x32(wa[s], fb, acc[1]);
     }
     // rows (dh, n) = 4 g + reg: dh = 2 g + (reg >> 1), n = reg & 1; output row q = r - dh + 3
 #pragma unroll

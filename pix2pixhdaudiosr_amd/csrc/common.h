@@ -74,6 +74,50 @@ __device__ __forceinline__ bool fold_arrive_last(unsigned* ticket, unsigned expe
 }
 #endif
 
+}  // namespace p2phd
+
+// ---- the library's 16-bit storage type ------------------------------------------------------------------------------------------
+// The same sources build two libraries: libp2phd_hip.so stores activations as bf16 (the benchmarked mode, BASELINE configs[1]),
+// libp2phd_hip_f16.so (-DP2PHD_F16) as IEEE fp16 -- the reference's actual AMP type (train.py:62-67: autocast + GradScaler; 11
+// significand bits against 8).  Both MFMA forms issue at the same rate (MI355X_MICROARCH.md, matrix cores), accumulate in f32, and
+// every kernel names the type `bf16_t` / the ABI's dtype code P2PHD_BF16 = "this library's 16-bit type" (p2phd_half_type() tells which).
+#ifdef P2PHD_F16
+typedef _Float16 p2phd_h16;
+#else
+typedef __bf16 p2phd_h16;
+#endif
+#ifdef __HIPCC__
+typedef __attribute__((ext_vector_type(8))) p2phd_h16 p2phd_h16x8;
+typedef __attribute__((ext_vector_type(16))) float p2phd_f32x16;
+typedef __attribute__((ext_vector_type(4))) float p2phd_f32x4;
+__device__ __forceinline__ p2phd_f32x16 p2phd_mfma_32x32x16(p2phd_h16x8 a, p2phd_h16x8 b, p2phd_f32x16 c) {
+#ifdef P2PHD_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ p2phd_f32x4 p2phd_mfma_16x16x32(p2phd_h16x8 a, p2phd_h16x8 b, p2phd_f32x4 c) {
+#ifdef P2PHD_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+// the two 16-bit values packed in one dword, widened to f32
+__device__ __forceinline__ void p2phd_unpack2(unsigned w, float& lo, float& hi) {
+#ifdef P2PHD_F16
+  lo = (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu));
+  hi = (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+#else
+  lo = __uint_as_float(w << 16);
+  hi = __uint_as_float(w & 0xFFFF0000u);
+#endif
+}
+#endif
+
+namespace p2phd {
+
 inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

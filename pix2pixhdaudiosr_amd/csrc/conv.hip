@@ -37,9 +37,9 @@ namespace {
 
 using p2phd::GDesc;
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
+typedef __attribute__((ext_vector_type(4))) bf16_t bf16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -327,8 +327,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_ABL_NOMFMA
       asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
 #else
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
-                                                          *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j], 0, 0, 0);
+      acc[i][j] = p2phd_mfma_32x32x16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
+                                                          *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j]);
 #endif
     } else {
       // exact f32 MFMA; any k permutation is fine as long as A and B share it
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
       uint2* gp = reinterpret_cast<uint2*>(&g8);
       ap[0] = af[buf][i][0]; ap[1] = af[buf][i][1];
       gp[0] = gf[buf][j][0]; gp[1] = gf[buf][j][1];
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, g8, acc[i][j], 0, 0, 0);
+      acc[i][j] = p2phd_mfma_32x32x16(a8, g8, acc[i][j]);
     };
     constexpr int NSUB = BKP / 16;
 #ifdef P2PHD_PROBE

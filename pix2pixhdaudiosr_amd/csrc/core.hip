@@ -114,6 +114,14 @@ extern "C" int p2phd_set_option(const char* name, int value) {
 
 extern "C" const char* p2phd_last_error(void) { return p2phd::g_err; }
 extern "C" int p2phd_abi_version(void) { return 1; }
+// 1: this library's 16-bit storage type (dtype code P2PHD_BF16) is bf16; 2: IEEE fp16 (the -DP2PHD_F16 build, libp2phd_hip_f16.so)
+extern "C" int p2phd_half_type(void) {
+#ifdef P2PHD_F16
+  return 2;
+#else
+  return 1;
+#endif
+}
 
 extern "C" int p2phd_device_info(char* name, int cap) {
   int dev = 0;

@@ -8,7 +8,7 @@
 
 namespace {
 
-typedef __bf16 bf16_t;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);
@@ -138,7 +138,14 @@ inline int grid_for(long work, int cap = 2048) { return (int)std::max<long>(1, s
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                        float* __restrict__ v, long n, const float* __restrict__ lr_dev,
                                                        const long long* __restrict__ step_dev, float b1, float b2, float eps,
-                                                       float gscale) {
+                                                       float gscale, const float* __restrict__ scaler, int found_idx) {
+  // loss scaling (fp16 storage): gradients arrive multiplied by scaler[0]; scaler[1] = 1 / scale; a non-finite gradient
+  // anywhere in this buffer (scaler[3 + found_idx], set by grads_nonfinite_kernel) skips the whole update, as
+  // torch.cuda.amp.GradScaler.step does (train.py:165-181)
+  if (scaler != nullptr) {
+    if (scaler[3 + found_idx] != 0.f) return;
+    gscale *= scaler[1];
+  }
   const double t = (double)(*step_dev + 1);
   const float lr = *lr_dev;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
@@ -180,7 +187,39 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, co
   }
 }
 
-__global__ void adam_tick_kernel(long long* step_dev) { *step_dev += 1; }
+__global__ void adam_tick_kernel(long long* step_dev, const float* scaler, int found_idx) {
+  if (scaler == nullptr || scaler[3 + found_idx] == 0.f) *step_dev += 1;          // a skipped update does not count
+}
+
+// flag[0] = 1 if any of g[0..n) is inf or nan (every thread that sees one stores the same value: no atomics)
+__global__ __launch_bounds__(256) void grads_nonfinite_kernel(const float* __restrict__ g, long n, float* __restrict__ flag) {
+  typedef __attribute__((ext_vector_type(4))) float f4v;
+  bool bad = false;
+  const long n4 = n >> 2, stride = (long)gridDim.x * 256;
+  for (long e0 = (long)blockIdx.x * 256 + threadIdx.x; e0 < n4; e0 += 4 * stride) {
+    f4v q[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) q[u] = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(g) + min(e0 + u * stride, n4 - 1));
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bad |= !(fabsf(q[u][k]) <= 3.4e38f);             // false for inf and for nan
+  }
+  for (long e = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) bad |= !(fabsf(g[e]) <= 3.4e38f);
+  if (bad) *flag = 1.f;
+}
+
+// GradScaler.update(): state = (scale, 1 / scale, growth tracker, found_0, found_1, ...)
+__global__ void scaler_update_kernel(float* state, float growth, float backoff, float interval) {
+  const bool found = state[3] != 0.f || state[4] != 0.f;
+  float scale = state[0], tracker = state[2];
+  if (found) { scale *= backoff; tracker = 0.f; }
+  else {
+    tracker += 1.f;
+    if (tracker >= interval) { scale *= growth; tracker = 0.f; }
+  }
+  state[0] = scale; state[1] = 1.f / scale; state[2] = tracker; state[3] = 0.f; state[4] = 0.f;
+}
 
 // base[off .. off + len) = 0 for every (off, len) pair: one launch for all the small segments of a flat buffer
 __global__ __launch_bounds__(256) void zero_segments_kernel(float* __restrict__ base, const long long* __restrict__ seg, int n) {
@@ -237,19 +276,44 @@ extern "C" int p2phd_adam_step(float* params, const float* grads, float* exp_avg
   return p2phd::check_launch("adam_step");
 }
 
+static int adam_step_dev_impl(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, const float* lr_dev,
+                              int64_t* step_dev, float beta1, float beta2, float eps, float grad_scale, float* scaler, int found_idx,
+                              void* stream) {
+  P2PHD_REQUIRE(n >= 0, "adam_step_dev: negative size");
+  P2PHD_REQUIRE(lr_dev && step_dev, "adam_step_dev: null state pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0) {
+    P2PHD_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step_dev: null pointer");
+    if (scaler != nullptr)
+      hipLaunchKernelGGL(grads_nonfinite_kernel, dim3(grid_for((n + 3) / 4, 2048)), dim3(256), 0, st, grads, (long)n, scaler + 3 + found_idx);
+    const dim3 grid(grid_for((n + 3) / 4, 4096));
+    hipLaunchKernelGGL(adam_dev_kernel, grid, dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
+                       reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale, (const float*)scaler, found_idx);
+  }
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<long long*>(step_dev), (const float*)scaler, found_idx);
+  return p2phd::check_launch("adam_step_dev");
+}
+
 extern "C" int p2phd_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                                    const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
                                    float grad_scale, void* stream) {
-  P2PHD_REQUIRE(n >= 0, "adam_step_dev: negative size");
-  P2PHD_REQUIRE(lr_dev && step_dev, "adam_step_dev: null state pointer");
-  if (n > 0) {
-    P2PHD_REQUIRE(params && grads && exp_avg && exp_avg_sq, "adam_step_dev: null pointer");
-    const dim3 grid(grid_for((n + 3) / 4, 4096));
-    hipLaunchKernelGGL(adam_dev_kernel, grid, dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, (long)n, lr_dev,
-                       reinterpret_cast<const long long*>(step_dev), beta1, beta2, eps, grad_scale);
-  }
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<long long*>(step_dev));
-  return p2phd::check_launch("adam_step_dev");
+  return adam_step_dev_impl(params, grads, exp_avg, exp_avg_sq, n, lr_dev, step_dev, beta1, beta2, eps, grad_scale, nullptr, 0, stream);
+}
+
+extern "C" int p2phd_adam_step_scaled(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                      const float* lr_dev, int64_t* step_dev, float beta1, float beta2, float eps,
+                                      float grad_scale, float* scaler_state, int found_index, void* stream) {
+  P2PHD_REQUIRE(scaler_state != nullptr && (found_index == 0 || found_index == 1), "adam_step_scaled: bad scaler arguments");
+  return adam_step_dev_impl(params, grads, exp_avg, exp_avg_sq, n, lr_dev, step_dev, beta1, beta2, eps, grad_scale, scaler_state,
+                            found_index, stream);
+}
+
+extern "C" int p2phd_scaler_update(float* scaler_state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+  P2PHD_REQUIRE(scaler_state != nullptr && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval >= 1,
+                "scaler_update: bad arguments");
+  hipLaunchKernelGGL(scaler_update_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, scaler_state, growth_factor, backoff_factor,
+                     (float)growth_interval);
+  return p2phd::check_launch("scaler_update");
 }
 
 extern "C" int p2phd_zero_segments(float* base, const int64_t* seg_dev, int n, void* stream) {

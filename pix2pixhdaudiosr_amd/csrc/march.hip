@@ -24,8 +24,8 @@ namespace {
 
 using namespace p2phd;
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -81,11 +81,16 @@ __device__ __forceinline__ u32x4 lazy_norm8(u32x4 raw, const float* tab, int c0,
   for (int h = 0; h < 4; ++h) {                                   // dword h = channels c0 + 2 h, c0 + 2 h + 1
     const f32x4 t = *reinterpret_cast<const f32x4*>(tab + 2 * (c0 + 2 * h));   // (mean0, rstd0, mean1, rstd1)
     const unsigned w = raw[h];
-    f32x2 v = {__uint_as_float(w << 16), __uint_as_float(w & 0xFFFF0000u)};
+    f32x2 v;
+    {
+      float lo, hi;
+      p2phd_unpack2(w, lo, hi);
+      v = f32x2{lo, hi};
+    }
     v = (v - f32x2{t[0], t[2]}) * f32x2{t[1], t[3]};
     if (slope == 0.f) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); }                 // (uniform branch)
     else { v[0] = v[0] > 0.f ? v[0] : slope * v[0]; v[1] = v[1] > 0.f ? v[1] : slope * v[1]; }
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
     const bf16x2 r = {(bf16_t)v[0], (bf16_t)v[1]};
     o[h] = ok ? *reinterpret_cast<const unsigned*>(&r) : 0u;
   }
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
 #pragma unroll
         for (int b = 0; b < MBW; ++b) {
           const bf16x8 af = *reinterpret_cast<const bf16x8*>(rowp + aoff[ii] + b * 32 * PXB);
-          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[r * KSR + ii], acc[b], 0, 0, 0);
+          acc[b] = p2phd_mfma_16x16x32(af, bfrag[r * KSR + ii], acc[b]);
         }
       }
     }
@@ -594,7 +599,7 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
           for (int kk = 0; kk < KN; ++kk) {
             const char* rp = (d >> 1) ? row1 : row0;
             const bf16x8 af = *reinterpret_cast<const bf16x8*>(rp + b * 16 * PXB + (d & 1) * PXB + kk * 64);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfrag[d * KN + kk], acc, 0, 0, 0);
+            acc = p2phd_mfma_16x16x32(af, bfrag[d * KN + kk], acc);
           }
         finish(acc, b, 1, 1, 0);
       }
@@ -607,11 +612,11 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
           const bf16x8 a00 = *reinterpret_cast<const bf16x8*>(row0 + b * 16 * PXB + kk * 64);
           const bf16x8 a01 = *reinterpret_cast<const bf16x8*>(row0 + b * 16 * PXB + PXB + kk * 64);
           const bf16x8 a10 = *reinterpret_cast<const bf16x8*>(row1 + b * 16 * PXB + kk * 64);
-          c00 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[kk], c00, 0, 0, 0);
-          c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[KN + kk], c01, 0, 0, 0);
-          c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, bfrag[3 * KN + kk], c10, 0, 0, 0);
-          c01 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, bfrag[2 * KN + kk], c01, 0, 0, 0);
-          c10 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, bfrag[4 * KN + kk], c10, 0, 0, 0);
+          c00 = p2phd_mfma_16x16x32(a00, bfrag[kk], c00);
+          c01 = p2phd_mfma_16x16x32(a00, bfrag[KN + kk], c01);
+          c10 = p2phd_mfma_16x16x32(a00, bfrag[3 * KN + kk], c10);
+          c01 = p2phd_mfma_16x16x32(a01, bfrag[2 * KN + kk], c01);
+          c10 = p2phd_mfma_16x16x32(a10, bfrag[4 * KN + kk], c10);
         }
         finish(c00, b, 0, 0, 0);
         finish(c01, b, 0, 1, 1);
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(kThreads) void march_w_kernel(const MarchWArgs a) {
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const bf16x8 bfr = tr_pair(B + 2 * (32 * kk) * PX48, B + 2 * (32 * kk + 16) * PX48);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk], bfr, acc[i], 0, 0, 0);
+            acc[i] = p2phd_mfma_16x16x32(af[kk], bfr, acc[i]);
           }
         }
       }

@@ -11,7 +11,7 @@ namespace {
 
 using p2phd::fold_store;
 using p2phd::fold_load;
-typedef __bf16 bf16_t;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
 template <typename T> struct Elem;
 template <> struct Elem<float> { static constexpr int EPP = 4; };
 template <> struct Elem<bf16_t> { static constexpr int EPP = 8; };

@@ -16,8 +16,8 @@
 
 namespace {
 
-typedef __bf16 bf16_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
+typedef __attribute__((ext_vector_type(8))) bf16_t bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 constexpr int RT = 8;                      // grid rows per tile
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinDesc d, const
             uint2* bp = reinterpret_cast<uint2*>(&b8);
             ap[0] = af[i][0]; ap[1] = af[i][1];
             bp[0] = bf[j][0]; bp[1] = bf[j][1];
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[i][j], 0, 0, 0);
+            acc[i][j] = p2phd_mfma_32x32x16(a8, b8, acc[i][j]);
           }
       }
     }

@@ -13,7 +13,7 @@
 
 namespace {
 
-typedef __bf16 bf16_t;
+typedef p2phd_h16 bf16_t;                 // the library's 16-bit storage type: bf16, or fp16 in the -DP2PHD_F16 build (common.h)
 __device__ __forceinline__ float to_f(float v) { return v; }
 __device__ __forceinline__ float to_f(bf16_t v) { return (float)v; }
 template <typename T> __device__ __forceinline__ T from_f(float v);

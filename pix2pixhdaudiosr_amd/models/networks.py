@@ -222,7 +222,7 @@ def _run(steps, x, residual_last=None, cuts=None, cut_after=(), first_exclusive=
         if isinstance(s, _ConvStep):
             # the next step normalises on load (csrc/march.hip): this one hands out its raw output + statistics (_ops.LazyNorm)
             nxt = steps[j + 1] if j + 1 < len(steps) else None
-            defer = (isinstance(nxt, _ConvStep) and s.spec.norm and x.dtype == torch.bfloat16 and _ops.lazy_static_ok(nxt.spec)
+            defer = (isinstance(nxt, _ConvStep) and s.spec.norm and x.dtype in _ops.HALF_DTYPES and _ops.lazy_static_ok(nxt.spec)
                      and os.environ.get("P2PHD_LAZY", "1") != "0")
             x = s.run(x, residual_last if j == len(steps) - 1 else None, exclusive=j > 0 or first_exclusive, defer=defer)
         else:
@@ -287,7 +287,7 @@ def _centered_input(net, x):
     10-25 per channel, so rounding x itself to 8 mantissa bits is noise of 5-10 % of the channel's SIGNAL, and the raw conv
     output (stored in bf16 before its normalisation) carries the same offset.  Centred, both are rounded relative to the
     signal.  Measured at configs[1] size: generated spectrogram bf16-vs-fp32 error 1.2e-1 -> see tests/test_gpu_fullsize.py."""
-    if net._dtype() != torch.bfloat16:
+    if net._dtype() not in _ops.HALF_DTYPES:
         return x
     first = _flat_conv_steps(net._steps(net._first_seq))[0].spec
     if not (first.norm and first.pad_mode == 1):

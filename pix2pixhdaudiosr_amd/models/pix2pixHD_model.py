@@ -86,7 +86,12 @@ class Pix2PixHDModel(BaseModel):
         self.isTrain = opt.isTrain
         self.use_features = False
         self.gen_features = False
-        self.compute_dtype = torch.bfloat16 if _opt(opt, 'fp16', False) else torch.float32
+        # --fp16 = 16-bit activation storage with fp32 accumulation and fp32 master weights.  Default bf16 (the benchmarked mode,
+        # BASELINE configs[1]); opt.fp16_storage = True: IEEE fp16, the reference's actual autocast type (train.py:62-67), served
+        # by the fp16 build of the library (libp2phd_hip_f16.so) with a device-resident loss scaler (optim.DeviceGradScaler)
+        self.compute_dtype = torch.float32
+        if _opt(opt, 'fp16', False):
+            self.compute_dtype = torch.float16 if _opt(opt, 'fp16_storage', False) else torch.bfloat16
         input_nc = opt.input_nc
 
         ##### transform
@@ -151,6 +156,7 @@ class Pix2PixHDModel(BaseModel):
             if verbose:
                 print('Total number of parameters of D: %d' % (sum([param.numel() for param in params])))
             self.optimizer_D = FlatAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
+            self._attach_scaler()
         self._visual = None
 
     # ------------------------------------------------------------------------------------------
@@ -428,6 +434,15 @@ class Pix2PixHDModel(BaseModel):
             self._bucket_plan_cache = plan
         return plan[0][0], plan[1], plan[2]
 
+    def _attach_scaler(self):
+        """fp16 storage: one device-resident loss scaler for both optimisers (train.py:62-67); none otherwise."""
+        from ..optim import DeviceGradScaler
+        self.scaler = None
+        if self.compute_dtype == torch.float16:
+            self.scaler = DeviceGradScaler(self.device, init_scale=float(_opt(self.opt, 'loss_scale', 65536.0)))
+        for idx, o in enumerate((self.optimizer_G, self.optimizer_D)):
+            o.scaler, o.scaler_index = self.scaler, idx
+
     def _phase_a_forward(self, lr_audio, hr_audio, noise=None):
         """Forward of G and D, all losses, zeroed gradient buffers.  Returns the loss dict; the generator backward is
         then run stage by stage with `_g_stages()`."""
@@ -435,6 +450,8 @@ class Pix2PixHDModel(BaseModel):
         ld = dict(zip(self.loss_names, losses))
         self._loss_D = (ld['D_fake'] + ld['D_real']) * 0.5
         self._loss_G = ld['G_GAN'] + ld.get('G_GAN_Feat', 0) + ld.get('G_mat', 0)
+        if self.scaler is not None:                                # scaler.scale(loss).backward() of train.py:165-181
+            self._loss_D, self._loss_G = self.scaler.scale(self._loss_D), self.scaler.scale(self._loss_G)
         self.optimizer_G.zero_grad(lazy=True)                       # (first weight gradient of the step overwrites: no memset)
         self.optimizer_D.zero_grad(lazy=True)
         self.optimizer_G.bucket_log = []
@@ -527,8 +544,10 @@ class Pix2PixHDModel(BaseModel):
         ld = self._phase_a(lr_audio, hr_audio, noise)              # G buckets are in flight: they overlap the D backward
         self._phase_b()
         self.optimizer_D.reduce_gradients_async()
-        self.optimizer_G.step()
-        self.optimizer_D.step()
+        self.optimizer_G.step(use_scaler=True)
+        self.optimizer_D.step(use_scaler=True)
+        if self.scaler is not None:
+            self.scaler.update()                                   # once per iteration (train.py:181)
         return ld
 
     # ------------------------------------------------------------------------------------------
@@ -591,10 +610,12 @@ class Pix2PixHDModel(BaseModel):
                 self._phase_b()
                 gB.capture_end()
                 gCg.capture_begin(pool=g0.pool(), capture_error_mode=mode)
-                optG.step_local()
+                optG.step_local(use_scaler=True)
                 gCg.capture_end()
                 gCd.capture_begin(pool=g0.pool(), capture_error_mode=mode)
-                optD.step_local()
+                optD.step_local(use_scaler=True)
+                if self.scaler is not None:
+                    self.scaler.update()
                 gCd.capture_end()
             torch.cuda.current_stream().wait_stream(side)
             optG.step_count -= 1                                   # capture records, it does not execute
@@ -629,6 +650,7 @@ class Pix2PixHDModel(BaseModel):
         optimiser's buffers are dropped; data-parallel settings carry over."""
         old = self.optimizer_G
         self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
+        self.optimizer_G.scaler, self.optimizer_G.scaler_index = getattr(self, 'scaler', None), 0
         if getattr(old, '_collectives', False) or old.world_size > 1:
             self.optimizer_G.enable_data_parallel(old.world_size, old.process_group, getattr(old, '_collectives', False) and old.world_size == 1)
         self._graph_state = None

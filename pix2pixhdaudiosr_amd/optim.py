@@ -13,6 +13,29 @@ import torch
 from . import _lib, _ops
 
 
+class DeviceGradScaler:
+    """torch.cuda.amp.GradScaler (train.py:62-67,165-181: ONE scaler for both losses) with its state on the device, so that the
+    captured training step replays unchanged: `scale(loss)` multiplies by the current scale (read from device memory by the
+    kernel), FlatAdam.step_local scans its gradient buffer for inf / nan, unscales inside the Adam kernel and skips the update
+    on a non-finite gradient, `update()` applies backoff / growth.  Used with fp16 storage; bf16 and fp32 need none."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.zeros(8, dtype=torch.float32, device=device)
+        self.state[0] = float(init_scale)
+        self.state[1] = 1.0 / float(init_scale)
+        self.growth_factor, self.backoff_factor, self.growth_interval = float(growth_factor), float(backoff_factor), int(growth_interval)
+
+    def scale(self, loss):
+        return loss * self.state[0]
+
+    def update(self):
+        _lib.check(_lib.lib().p2phd_scaler_update(_lib.ptr(self.state), self.growth_factor, self.backoff_factor, self.growth_interval,
+                                                  _lib.stream_ptr()), "scaler_update")
+
+    def get_scale(self):
+        return float(self.state[0].item())
+
+
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, process_group=None):
         params = [p for p in params]
@@ -187,27 +210,37 @@ class FlatAdam(torch.optim.Optimizer):
         return {"waits": self._waits, "exposed_stream_ms": float(ms), "host_wait_ms": self._wait_host_s * 1e3}
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, use_scaler=False):
         if closure is not None:
             raise NotImplementedError("closures are not supported")
         self._install_grad_views()
         if self._collectives:
             self.reduce_gradients_async()
             self.wait_gradients()
-        self.step_local()
+        self.step_local(use_scaler)
 
     @torch.no_grad()
-    def step_local(self):
-        """The update itself, without the data-parallel exchange (graph-capturable: every argument is constant)."""
+    def step_local(self, use_scaler=False):
+        """The update itself, without the data-parallel exchange (graph-capturable: every argument is constant).
+        `use_scaler`: the gradients carry the attached DeviceGradScaler's scale (Pix2PixHDModel.train_step with fp16 storage);
+        a caller that runs torch's own GradScaler (train.py's loop) hands over unscaled gradients and leaves it False."""
         g = self.param_groups[0]
         self._flush_fresh()
         self.sync_hyper()
         self.step_count += 1
         b1, b2 = g["betas"]
-        _lib.check(_lib.lib().p2phd_adam_step_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
-                                                  _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
-                                                  _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
-                                                  1.0 / self.world_size, _lib.stream_ptr()), "adam_step")
+        sc = getattr(self, "scaler", None) if use_scaler else None
+        if sc is not None:                                         # fp16 storage: scaled gradients, skip on inf / nan (DeviceGradScaler)
+            _lib.check(_lib.lib().p2phd_adam_step_scaled(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
+                                                         _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
+                                                         _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
+                                                         1.0 / self.world_size, _lib.ptr(sc.state), int(self.scaler_index),
+                                                         _lib.stream_ptr()), "adam_step_scaled")
+        else:
+            _lib.check(_lib.lib().p2phd_adam_step_dev(_lib.ptr(self.flat_p), _lib.ptr(self.flat_g), _lib.ptr(self.exp_avg),
+                                                      _lib.ptr(self.exp_avg_sq), self._total, _lib.ptr(self.lr_dev),
+                                                      _lib.ptr(self.step_dev), float(b1), float(b2), float(g["eps"]),
+                                                      1.0 / self.world_size, _lib.stream_ptr()), "adam_step")
         _ops.bump_weight_epoch()
 
     def sync_hyper(self):

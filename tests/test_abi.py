@@ -26,6 +26,12 @@ def test_header_symbols_exported_and_bound():
     for s in syms:
         assert hasattr(L, s), s
     assert _lib.lib().p2phd_abi_version() >= 1
+    # the fp16 build (the same sources, 16-bit type = IEEE half): the same exports, told apart by p2phd_half_type()
+    assert os.path.isfile(_lib.LIB_PATH_F16), "build the extension first: __graft_entry__.build()"
+    L16 = ctypes.CDLL(_lib.LIB_PATH_F16)
+    for s in syms:
+        assert hasattr(L16, s), s
+    assert (_lib.lib().p2phd_half_type(), _lib.lib("f16").p2phd_half_type()) == (1, 2)
 
 
 def test_host_only_entry_points():

@@ -119,7 +119,7 @@ def conv_case_errors(case, dtype, seed):
     assert tuple(y.shape) == tuple(yo_shape)
     grd = torch.autograd.grad((y * cot.cuda()).sum(), [xd, wd, bd] + ([rd] if use_res else []))
 
-    q = (lambda t: t.bfloat16().float()) if dtype == torch.bfloat16 else (lambda t: t)
+    q = (lambda t: t.to(dtype).float()) if dtype in (torch.bfloat16, torch.float16) else (lambda t: t)
     xo, wo, bo = (t.clone().requires_grad_(True) for t in (q(x), q(w), b))
     res_o = q(res).clone().requires_grad_(True) if use_res else None
     mask = (y.detach().cpu() > 0) if act in SLOPE else None
@@ -158,12 +158,14 @@ def conv_case_errors(case, dtype, seed):
 # within the rounding of the path of zero -- fp32: 1e-5 of the RMS pre-activation (accumulation order; at most a handful
 # of elements), bf16: 3e-2 (the raw conv output is stored in bf16 before the normalisation: 2^-8 relative on values up to
 # several RMS) and at most 2 % of the elements.
+# fp16 storage (round 4: the fp16 build of the library, 11 significand bits): an eighth of the bf16 bounds, measured the same way.
 TOL = {torch.float32: dict(y=1e-4, g=3e-4, g_tiny=3e-4, db=1e-6, db_norm=1e-4, flip_pre=1e-5, flip_share=1e-4),
-       torch.bfloat16: dict(y=1e-2, g=1.2e-2, g_tiny=2.5e-2, db=8e-3, db_norm=2.5e-2, flip_pre=3e-2, flip_share=2e-2)}
+       torch.bfloat16: dict(y=1e-2, g=1.2e-2, g_tiny=2.5e-2, db=8e-3, db_norm=2.5e-2, flip_pre=3e-2, flip_share=2e-2),
+       torch.float16: dict(y=1.5e-3, g=2e-3, g_tiny=4e-3, db=1e-3, db_norm=4e-3, flip_pre=4e-3, flip_share=3e-3)}
 TINY_PLANES = {"c3_reflect_2x2"}
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_conv_block(case, dtype):
     name, norm = case[0], case[9]

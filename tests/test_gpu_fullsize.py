@@ -160,8 +160,11 @@ def test_three_scale_discriminator_against_reference(dtype, tol, gtol):
             assert_grad_close(f"{tag}:{k}", gr.cpu().numpy(), g[f"{tag}_g_{k}"], rtol=gtol, noise_biases=nb)
 
 
-def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size():
-    """The benchmarked mode at the benchmarked geometry: configs[1]'s networks (real widths, 512x256, two samples) in bf16
+@pytest.mark.parametrize("half", ["bf16", "fp16"])
+def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size(half):
+    """(`fp16`, round 4: the reference's actual AMP storage type -- opt.fp16_storage, the fp16 build of the library, loss scaled
+    by 2^16 as torch.cuda.amp.GradScaler starts -- must track the fp32 step far closer: 11 significand bits against 8.)
+    The benchmarked mode at the benchmarked geometry: configs[1]'s networks (real widths, 512x256, two samples) in bf16
     against the SAME step in fp32 on the HIP path (itself checked against the oracle above): losses, generated spectrogram
     and every weight gradient of both backward passes (what the direction-only checks on the 2-8-channel golden nets,
     test_gpu_networks.py, cannot say about the real widths)."""
@@ -173,20 +176,23 @@ def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size():
     pD = OM.N.init_params(OM.netD_spec(oo), seed=2)
     hr, lr, _ = OM.synthetic_batch(2, oo, seed=6)
     res = {}
-    for name, fp16 in (("f32", False), ("bf16", True)):
-        m = create_model(_opt(fp16=fp16))
+    for name, kw in (("f32", dict(fp16=False)), (half, dict(fp16=True, fp16_storage=half == "fp16"))):
+        m = create_model(_opt(**kw))
+        assert m.compute_dtype == {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[name]
         _load_from(m.netG, pG); _load_from(m.netD, pD)
         _ops.bump_weight_epoch()
         losses, sr = m.forward(lr, None, hr, None, infer=True)
         got = dict(zip(m.loss_names, losses))
-        m.optimizer_G.zero_grad(); (got["G_GAN"] + got["G_GAN_Feat"]).backward(retain_graph=True)
-        gG = {k: p.grad.detach().float().cpu().clone() for k, p in m.netG.named_parameters()}
-        m.optimizer_D.zero_grad(); ((got["D_fake"] + got["D_real"]) * 0.5).backward()
-        gD = {k: p.grad.detach().float().cpu().clone() for k, p in m.netD.named_parameters()}
+        S = 65536.0 if name == "fp16" else 1.0                      # GradScaler's initial scale (train.py:62-67)
+        m.optimizer_G.zero_grad(); ((got["G_GAN"] + got["G_GAN_Feat"]) * S).backward(retain_graph=True)
+        gG = {k: p.grad.detach().float().cpu().clone() / S for k, p in m.netG.named_parameters()}
+        m.optimizer_D.zero_grad(); ((got["D_fake"] + got["D_real"]) * (0.5 * S)).backward()
+        gD = {k: p.grad.detach().float().cpu().clone() / S for k, p in m.netD.named_parameters()}
+        assert all(torch.isfinite(v).all() for v in list(gG.values()) + list(gD.values())), name
         res[name] = ({k: float(v) for k, v in got.items()}, sr.detach().float().cpu(), gG, gD)
         del m
         torch.cuda.empty_cache()
-    (l32, sr32, gG32, gD32), (l16, sr16, gG16, gD16) = res["f32"], res["bf16"]
+    (l32, sr32, gG32, gD32), (l16, sr16, gG16, gD16) = res["f32"], res[half]
     for k in l32:
         assert abs(l16[k] - l32[k]) <= 2e-2 * max(1.0, abs(l32[k])), (k, l16[k], l32[k])
     e_sr = rel_err(sr16.numpy(), sr32.numpy())
@@ -202,8 +208,14 @@ def test_configs1_bf16_step_tracks_the_fp32_step_at_full_size():
         for e, c, name in worst:
             print(f"   {name:36s} rel err {e:.3f} cosine {c:.4f}")
     worst.sort(reverse=True)
-    print(f"bf16 vs fp32 at full size: sr rel err {e_sr:.2e}; worst weight-gradient rel err {worst[0][0]:.2e} ({worst[0][2]}), "
+    print(f"{half} vs fp32 at full size: sr rel err {e_sr:.2e}; worst weight-gradient rel err {worst[0][0]:.2e} ({worst[0][2]}), "
           f"median {worst[len(worst) // 2][0]:.2e}, min cosine {min(c for _, c, _ in worst):.4f}")
+    if half == "fp16":
+        # the round-3 review's bar for the reference's AMP type: cosine >= 0.97 at every generator layer, spectrogram <= 1.5e-2
+        assert e_sr < 1.5e-2, e_sr
+        assert min(c for _, c, _ in worst) >= 0.97, min(c for _, c, _ in worst)
+        assert max(e for e, _, _ in worst) < 2.5e-1
+        return
     # Measured: spectrogram 4.9e-2 (1.2e-1 before the generator input was centred, networks._centered_input);
     # discriminator gradients 1-8 %; generator gradients 9 % at the output layer growing to 50 % (cosine 0.87) at the
     # input layer -- not rounding of the gradient itself but ReLU masks: 3-5 % activation noise flips the branch of the

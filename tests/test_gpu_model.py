@@ -148,6 +148,56 @@ def test_bf16_step_runs_and_tracks_fp32(golden_model):
     assert all(torch.isfinite(p).all() for p in m.netG.parameters())
 
 
+def test_fp16_storage_step_with_the_device_loss_scaler(golden_model):
+    """opt.fp16_storage: IEEE fp16 activations (the reference's autocast type, train.py:62-67) through the fp16 build of the
+    library, with optim.DeviceGradScaler in the place of torch.cuda.amp.GradScaler.  (1) the forward tracks the fp32 golden
+    values closer than bf16 does; (2) one train_step moves the weights as the unscaled bf16/fp32 rule would (the scale never
+    reaches the update) and leaves the scale alone, growth tracker = 1; (3) a scale so large that the gradients overflow in fp16
+    skips BOTH updates, does not advance the step counters and halves the scale; (4) the captured step does the same."""
+    from pix2pixhdaudiosr_amd import _lib
+    g = golden_model
+    S0 = 1024.0        # these 8-channel nets on 2 clips have gradients ~1e2 x those of configs[1]: 65536 overflows (and backs off, as it should)
+    m = _model(g, fp16=True, fp16_storage=True, mask=False, loss_scale=S0)
+    assert m.compute_dtype == torch.float16 and m.scaler is not None and m.scaler.get_scale() == S0
+    assert _lib.lib_for(torch.float16).p2phd_half_type() != _lib.lib_for(torch.bfloat16).p2phd_half_type()
+    lr, hr = _fresh_audio(g)
+    f32 = _model(g, mask=False)
+    l32, sr32 = f32.forward(lr, None, hr, None, infer=True)
+    losses, sr = m.forward(lr, None, hr, None, infer=True)
+    for k, v, r in zip(m.loss_names, losses, l32):
+        assert abs(float(v) - float(r)) < 1.5e-2 * max(1.0, abs(float(r))), (k, float(v), float(r))
+    assert rel_err(sr.detach().float().cpu().numpy(), sr32.detach().cpu().numpy()) < 1.5e-2
+    # (2) one scaled step against one fp32 step from the same weights: Adam's first step is sign-like, so compare directions
+    w0 = m.optimizer_G.flat_p.clone()
+    m.train_step(lr, hr)
+    f32.train_step(lr, hr)
+    st = m.scaler.state.cpu()
+    assert float(st[0]) == S0 and float(st[2]) == 1.0 and float(st[3]) == 0.0 and float(st[4]) == 0.0, st
+    assert m.optimizer_G.steps_taken() == 1 and m.optimizer_D.steps_taken() == 1
+    d16, d32 = m.optimizer_G.flat_p - w0, f32.optimizer_G.flat_p - w0
+    strong = _signal_mask(f32, f32.optimizer_G) & (f32.optimizer_G.flat_g.abs() > 1e-2 * f32.optimizer_G.flat_g.abs().max())
+    assert float((torch.sign(d16[strong]) == torch.sign(d32[strong])).float().mean()) > 0.99
+    assert float(d16.abs().max()) <= 2e-4 * 1.001                   # |update| <= lr: the scale did not leak into the step
+    # (3) overflow: skip, back off
+    m.scaler.state[0] = 2.0 ** 60; m.scaler.state[1] = 2.0 ** -60
+    wG, wD = m.optimizer_G.flat_p.clone(), m.optimizer_D.flat_p.clone()
+    m.train_step(lr, hr)
+    assert torch.equal(wG, m.optimizer_G.flat_p) and torch.equal(wD, m.optimizer_D.flat_p)
+    assert m.optimizer_G.steps_taken() == 1 and m.optimizer_D.steps_taken() == 1
+    assert m.scaler.get_scale() == 2.0 ** 59 and float(m.scaler.state[2]) == 0.0
+    # (4) the captured step: same scaler state machine, replayed
+    m.scaler.state[0] = S0; m.scaler.state[1] = 1.0 / S0
+    for _ in range(4):
+        out = m.train_step_graphed(lr, hr)
+    assert m._graph_state['graphs'] is not None
+    assert all(np.isfinite(float(v)) for v in out.values())
+    assert m.optimizer_G.steps_taken() == 5 and float(m.scaler.state[2]) == 4.0 and m.scaler.get_scale() == S0
+    m.scaler.state[0] = 2.0 ** 60; m.scaler.state[1] = 2.0 ** -60
+    wG = m.optimizer_G.flat_p.clone()
+    m.train_step_graphed(lr, hr)
+    assert torch.equal(wG, m.optimizer_G.flat_p) and m.optimizer_G.steps_taken() == 5 and m.scaler.get_scale() == 2.0 ** 59
+
+
 def test_unsupported_configs_raise():
     from pix2pixhdaudiosr_amd.models.models import create_model
     with pytest.raises(NotImplementedError):
