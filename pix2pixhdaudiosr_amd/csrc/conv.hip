@@ -136,7 +136,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     sk_tile = r - sk_part * d.sk_tail;
     tile_id = d.sk_first + sk_tile;
   }
-  const int bx = tile_id % d.grid_m, by = tile_id / d.grid_m;
+  const int bx = tile_id % d.grid_m;
+  int by = tile_id / d.grid_m;
+  if (d.cls_skip != 0) by = (d.n_extent + BN - 1) / BN - 1 - by;    // deepest tiles (class (1,1): 4 taps) first, the 1-tap class last
   const int n = flat ? 0 : bx / mtiles;
   const int p_base = flat ? bx * BM : (bx - n * mtiles) * BM;
   const int p_end = flat ? d.N * npix : npix;                 // rows >= p_end are padding
@@ -157,7 +159,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     constexpr int TPR = NT / BM;                              // threads per row (2)
     int ta = 0, tb = tid / BM;
     while (tb >= ntw) { tb -= ntw; ++ta; }
+    const bool swap_taps = d.cls_skip != 0 && ((n0 / cls_cp) >> 1) == 1;   // 2 x 2 taps in the K order of a pi = 1 class row
     for (int t = tid / BM; t < T_taps; t += TPR) {
+      if (swap_taps) { ta = t & 1; tb = t >> 1; }
       int off = -1;
       if (nn >= 0) {
         int hi = ho * sh + dh0 + ta * dhs;
@@ -204,7 +208,12 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const int rbase = tid >> 3;                                 // rows rbase + RS i
   const int kchunk = (tid & 7) ^ ((rbase >> 1) & 7);          // logical 16-byte chunk of the K slab
   const int CpB = Cp * SZ;
-  const int nsteps_all = KK / BK;
+  int nsteps_all = KK / BK;
+  if (d.cls_skip != 0) {                                       // stop behind the taps of the tile's highest class
+    const int cls_hi = min(3, (n0 + BN - 1) / cls_cp);
+    const int ktaps = ((cls_hi >> 1) + 1) * ((cls_hi & 1) + 1);
+    nsteps_all = min(nsteps_all, (ktaps * Cp + BK - 1) / BK);
+  }
   const int s_begin = sk_part < 0 ? 0 : sk_part * d.sk_steps;     // first K slab of this workgroup
   const int nsteps = sk_part < 0 ? nsteps_all : min(d.sk_steps, nsteps_all - s_begin);
   int a_t, a_cB;
@@ -1505,7 +1514,8 @@ __global__ void pack_merged_kernel(GDesc d, const float* __restrict__ w, T* __re
     if (row < 4 * d.cls_cp && t < d.nth * d.ntw && c < C) {
       const int cls = row / d.cls_cp, k = row - cls * d.cls_cp;
       const int pi = cls >> 1, pj = cls & 1;
-      const int ta = t / d.ntw, tb = t - ta * d.ntw;
+      const int tt = d.cls_skip && pi == 1 ? ((t & 1) << 1 | (t >> 1)) : t;    // K position -> tap (GDesc::cls_skip)
+      const int ta = tt / d.ntw, tb = tt - ta * d.ntw;
       const int dh = d.dh0 + ta * d.dh_step, dw = d.dw0 + tb * d.dw_step;
       const int r = pi + pad - 2 * dh, s2 = pj + pad - 2 * dw;
       if (k < K && r >= 0 && r < R && s2 >= 0 && s2 < S) v = w[k * s_k + c * s_c + r * S + s2];
@@ -1798,7 +1808,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   // CUs this launch can occupy: the device's count (cached per device), or what the caller states with
   // p2phd_set_option("cus", n) when the step runs on a CU-masked stream (opt.comm_cus leaves some to the RCCL kernels)
   const int cus = p2phd::g_opt_cus > 0 ? p2phd::g_opt_cus : p2phd::device_cus();
-  if (p2phd::g_opt_splitk_tail != 0) {
+  if (p2phd::g_opt_splitk_tail != 0 && d.cls_skip == 0) {        // (tap-skipping tiles differ in depth: their order balances the rounds)
     const int nsteps = d.KK / (8 * Elem<T>::EPP);
     const int full = TT / cus * cus, tail = TT - full;
     // Cost model in microseconds (layer tables of profiles/r03_*): a K slab of a BM x BN tile at the rate one CU sustains in
@@ -1853,6 +1863,15 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // narrower tiles only for layers that would leave most of it empty
   if (d.n_extent == 0) d.n_extent = d.Cp_out;
   const int k = d.n_extent;
+  if constexpr (sizeof(T) == 2) {
+    if (d.cls_skip != 0) {                                     // (planned for this tile: merged_plan)
+      d.flat_m = 0;
+      return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+    }
+  } else if (d.cls_skip != 0) {
+    p2phd::set_error("gconv: a tap-skipping merged plan reached a non-16-bit launch");
+    return P2PHD_EINVAL;
+  }
   const int bn = k > 64 ? 128 : (k > 32 ? 64 : 32);
   const int npix = d.Hg * d.Wg;
   const int taps = d.nth * d.ntw;
@@ -1920,7 +1939,7 @@ namespace p2phd {
 // 256 x 128 tiles and loses more (D 128->256 <- 256->512 at B = 64: 735 + 40 us against 539 + 89 us for plain input
 // gradient + two-pass backward) than the saved pass is worth: p2phd_conv_dgrad_bsum_pays says no for such a layer.
 bool gconv_plain_launch_takes_256x256(const GDesc& d_in, int dtype) {
-  if (dtype != P2PHD_BF16) return false;
+  if (dtype != P2PHD_BF16 || d_in.cls_skip != 0) return false;
   const int k = d_in.n_extent ? d_in.n_extent : d_in.Cp_out;
   const int npix = d_in.Hg * d_in.Wg, taps = d_in.nth * d_in.ntw;
   const bool flat = npix % 256 != 0;

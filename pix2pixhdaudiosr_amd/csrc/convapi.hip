@@ -163,7 +163,7 @@ void transposed_plans(int N, int Hin, int Win, int Cin, int Hout, int Wout, int 
 // input-resolution pixel (a, b), GEMM columns = (class, channel), taps (dh, dw) in {lo..hi}^2 shared by all classes with
 // zero weights where a class does not use a tap.  The gathered tensor is read once instead of four times and a
 // workgroup writes whole runs of adjacent output pixels instead of every other one.
-bool merged_plan(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Kout, int R, int S, int pad, Plan* out) {
+bool merged_plan(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Kout, int R, int S, int pad, Plan* out, int dtype = P2PHD_F32) {
   // dh = (pi + pad - r) / 2 over all classes and kernel rows with (pi + pad - r) even
   int lo = 1 << 30, hi = -(1 << 30);
   for (int pi = 0; pi < 2; ++pi)
@@ -184,6 +184,17 @@ bool merged_plan(int N, int Hin, int Win, int Cin, int Hout, int Wout, int Kout,
   d.nth = hi - lo + 1; d.ntw = hi_w - lo_w + 1; d.dh0 = lo; d.dw0 = lo_w;
   d.KK = std::max(64, round_up(d.nth * d.ntw * d.Cp_in, 64));
   p.rows_pad = round_up(4 * d.Cp_out, 128);
+  // 3 x 3, stride 2, pad 1 (the generator's down path backwards, its up path forwards): class (pi,pj) uses (pi + 1)(pj + 1) of the
+  // 2 x 2 taps -- 9 of the 16 (class, tap) pairs; the rest multiplies packed zeros.  With per-class tap order the launch skips
+  // them (GDesc::cls_skip; gconv_kernel).  Needs the 256 x 192 tile (16-bit types) to sit inside one pi: cls_cp a multiple or a
+  // divisor (>= 96) of 192, and planes that fill 256-row tiles.
+  {
+    const long npix = (long)d.Hg * d.Wg;
+    const bool taps_3x3 = R == 3 && S == 3 && pad == 1 && d.nth == 2 && d.ntw == 2 && lo == 0 && lo_w == 0;
+    const bool aligned = d.cls_cp >= 96 && (d.cls_cp % 192 == 0 || 192 % d.cls_cp == 0);
+    d.cls_skip = g_opt_cls_skip != 0 && dtype == P2PHD_BF16 && taps_3x3 && aligned && npix % 256 == 0 && d.Cp_in % 32 == 0 &&
+                 (long)N * (npix / 256) * (d.n_extent / 192) >= 192 ? 1 : 0;
+  }
   *out = p;
   return true;
 }
@@ -247,14 +258,14 @@ void make_plans(const p2phd_conv_desc* c, int which, std::vector<Plan>& plans, W
   } else if (which == 0 && c->transposed) {
     Plan mp;
     *m = plain_map(c->K, c->C, RS, c->K * RS, c->S);                          // weight [C][K][R][S]
-    if (c->stride == 2 && merged_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->pad, &mp)) plans.push_back(mp);
+    if (c->stride == 2 && merged_plan(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->pad, &mp, c->dtype)) plans.push_back(mp);
     else transposed_plans(c->N, c->H, c->W, c->C, Ho, Wo, c->K, c->R, c->S, c->stride, c->pad, plans);
   } else if (which == 1 && !c->transposed) {
     const int P = c->pad_mode == 1 ? c->pad : 0;                               // reflect: gradient on the padded grid
     Plan mp;
     *m = plain_map(c->C, c->K, RS, c->C * RS, c->S);                          // weight [K][C][R][S]
     if (c->w_layout == 1) *m = plain_map(c->C, c->K, 1, c->C * RS, c->S, c->C);   // ... kept as [K][R][S][C]
-    if (c->stride == 2 && merged_plan(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->pad_mode == 1 ? 0 : c->pad, &mp))
+    if (c->stride == 2 && merged_plan(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->pad_mode == 1 ? 0 : c->pad, &mp, c->dtype))
       plans.push_back(mp);
     else
       transposed_plans(c->N, Ho, Wo, c->K, c->H + 2 * P, c->W + 2 * P, c->C, c->R, c->S, c->stride, c->pad_mode == 1 ? 0 : c->pad, plans);

@@ -19,6 +19,10 @@ struct GDesc {
   int cls_cp;                                 // > 0: merged sub-pixel launch, GEMM column = class * cls_cp + channel,
                                               //      class (pi,pj) = (col / cls_cp) writes output pixel (2*ho+pi, 2*wo+pj)
   int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
+  int cls_skip;                               // merged 2 x 2-tap launch of a 3 x 3 stride-2 op (round 4): class (pi,pj) only uses the taps
+                                              //   (ta <= pi, tb <= pj); the K order of a class row is [(0,0),(0,1),(1,0),(1,1)] for pi = 0 and
+                                              //   [(0,0),(1,0),(0,1),(1,1)] for pi = 1, so every class's taps are a PREFIX of its K rows and a
+                                              //   256 x 192 tile stops after the taps of its highest class (1, 2 or 4 instead of always 4)
   unsigned in_bytes, w_bytes;                 // extents of the gathered tensor / this launch's packed weights (buffer descriptors)
   int stats_slots;                            // slots per sample of the statistics table (set by the launcher)
   const float* out_scale;                     // fp8 operands: device pointer to the weights' de-quantisation factor
@@ -89,7 +93,7 @@ size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
-extern int g_opt_march;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
+extern int g_opt_march; extern int g_opt_cls_skip;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);

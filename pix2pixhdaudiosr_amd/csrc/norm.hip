@@ -6,6 +6,7 @@
 // Reference semantics: models/networks.py:22 (InstanceNorm2d, eps 1e-5, biased variance, no affine, no running
 // stats), :188,233 (ReLU), :342-358 (LeakyReLU 0.2), :165,308 (AvgPool2d), :252 (residual add).
 #include "common.h"
+namespace p2phd { extern int g_opt_wgrad_xcd; }   // 1 (default): XCD-aware workgroup order (core.hip)
 
 namespace {
 
@@ -276,16 +277,30 @@ template <typename T, int ITERS, int CGN>
 __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                const float* __restrict__ stats, T* __restrict__ dy, int HW,
                                                                int C, int Cp, float eps, int act, float* __restrict__ db,
-                                                               T* __restrict__ rx, int W) {
+                                                               T* __restrict__ rx, int W, int cblocks, int xcd_order) {
   constexpr int EPP = Elem<T>::EPP;
+  // 1-D launch of cblocks x N workgroups.  A workgroup reads 16 * CGN bytes of every pixel -- half a 128-byte line for CGN = 4 --,
+  // its neighbour in the channel direction the other half.  Workgroups are dealt round-robin over the 8 XCDs, so with the
+  // plain order both halves of every line were fetched by two different L2s; the bijective chunk remap (as in wgrad_kernel,
+  // conv.hip) puts a contiguous run of logical ids on each XCD, neighbours 8 dispatch slots apart.
+  int bxl, nl;
+  {
+    const int Wg = (int)gridDim.x;
+    int L = (int)blockIdx.x;
+    if (xcd_order) {
+      const int q = Wg >> 3, r = Wg & 7, xcd = L & 7, k = L >> 3;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    bxl = L % cblocks; nl = L / cblocks;
+  }
   // CGN piece columns x (256 / CGN) pixel slices per workgroup: CGN = 4 doubles the workgroups of a 64-channel block and
   // halves the registers a thread holds (the 8-column form ran 1.5 workgroups per CU on the trunk: latency-bound)
   constexpr int NSL = 256 / CGN;
   __shared__ float s_red[4][CGN][2 * EPP];
   __shared__ float s_tot[CGN][2 * EPP];
   const int tid = threadIdx.x, cg = tid & (CGN - 1), sl = tid / CGN, wave = tid >> 6;
-  const int n = blockIdx.y, cpr = Cp / EPP;
-  const int pc = blockIdx.x * CGN + cg;
+  const int n = nl, cpr = Cp / EPP;
+  const int pc = bxl * CGN + cg;
   const bool col_ok = pc < cpr;
   const size_t base = (size_t)n * HW * Cp + (size_t)(col_ok ? pc : 0) * EPP;
   const float nslope = neg_slope_of(act);
@@ -364,7 +379,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
     const int H = HW / W, EX = 2 * (W + 2) + 2 * H;
     const T* dyn = dy + (size_t)n * HW * Cp;
     for (int task = tid; task < EX * CGN; task += 256) {
-      const int e = task / CGN, pcx = blockIdx.x * CGN + (task - e * CGN);
+      const int e = task / CGN, pcx = bxl * CGN + (task - e * CGN);
       if (pcx >= cpr) continue;
       int hs[2], ws[2], nh = 1, nw = 1;
       int r, c;                                                  // expanded coordinates of this entry
@@ -404,7 +419,7 @@ __global__ __launch_bounds__(256) void in_act_bwd_fused_kernel(const T* __restri
     __syncthreads();
     if (tid < CGN * EPP) {
       const int c8 = tid / EPP, k = tid % EPP;
-      const int c = (blockIdx.x * CGN + c8) * EPP + k;
+      const int c = (bxl * CGN + c8) * EPP + k;
       if (c < C) atomicAdd(&db[c], s_red[0][c8][k] + s_red[1][c8][k] + s_red[2][c8][k] + s_red[3][c8][k]);
     }
   }
@@ -852,8 +867,8 @@ static int instnorm_act_bwd_impl(int dtype, const void* g, const void* y, const 
   const int cblocks4 = (Cp / epp + 3) / 4;
   P2PHD_REQUIRE(!sums_given || !bwd_single_launch(dtype, N, HW, C), "instnorm_act_bwd_apply: this plane takes the single-launch backward (p2phd_instnorm_act_bwd_two_pass)");
   if (bwd_single_launch(dtype, N, HW, C)) {
-    dim3 fgrid((unsigned)cblocks4, (unsigned)N);
-#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db, (TT*)rx, W)
+    dim3 fgrid((unsigned)cblocks4 * (unsigned)N);
+#define P2PHD_FUSED_BWD(TT, IT) hipLaunchKernelGGL((in_act_bwd_fused_kernel<TT, IT, 4>), fgrid, dim3(256), 0, st, (const TT*)g, (const TT*)y, stats, (TT*)dy, (int)HW, C, Cp, eps, act, db, (TT*)rx, W, cblocks4, p2phd::g_opt_wgrad_xcd)
     if (dtype == P2PHD_BF16) { if (HW <= 512) P2PHD_FUSED_BWD(bf16_t, 8); else P2PHD_FUSED_BWD(bf16_t, 10); }
     else if (dtype == P2PHD_F32) { if (HW <= 512) P2PHD_FUSED_BWD(float, 8); else P2PHD_FUSED_BWD(float, 10); }
     else { p2phd::set_error("instnorm_act_bwd: unsupported dtype %d", dtype); return P2PHD_EUNSUPPORTED; }

@@ -54,6 +54,12 @@ CASES = [
     ("march_s_48to96_2strips", 48, 96, 3, 2, 1, 0, False, 0, True, 3, (1, 24, 256), False),   # 2 strips x 3 segments
     ("march_ct_96to48", 96, 48, 3, 2, 1, 0, True, 1, True, 3, (2, 8, 64), False),        # its dgrad is the 48 -> 96 gather
     ("march_ct_96to48_2strips", 96, 48, 3, 2, 1, 0, True, 1, True, 3, (1, 12, 128), False),
+    # round 4: merged sub-pixel launches of the 3x3 stride-2 layers that stop behind the taps of the tile's class (GDesc::cls_skip;
+    # 16-bit types, >= 192 tiles of 256 x 192): ConvTranspose2d forward with class pitch 96 (two classes per tile) and 192 (one),
+    # and the input gradient of the Conv2d
+    ("skip_ct_192to96", 192, 96, 3, 2, 1, 0, True, 1, True, 3, (8, 64, 64), False),
+    ("skip_ct_384to192", 384, 192, 3, 2, 1, 0, True, 1, True, 3, (4, 64, 64), False),
+    ("skip_s2_96to192", 96, 192, 3, 2, 1, 0, False, 0, True, 3, (8, 128, 128), False),
 ]
 
 

@@ -115,7 +115,7 @@ def test_fp8_forward_of_wide_layers():
     assert worst > 0.9, worst
     # a fp8 layer really ran on the fp8 entry point: its packed e4m3 weights exist and decode back to the master weights
     sp = [s for s in PN._flat_conv_steps(q._steps('model')) if s.spec.fp8][0]
-    buf = sp.spec._packed[("fp8", 1)][1]
+    buf = sp.spec._packed[("fp8", torch.bfloat16)][1]
     w = sp.conv.weight.detach()
     K, Cc = w.shape[0], w.shape[1]
     scale = buf[buf.numel() - 256:buf.numel() - 252].view(torch.float32).item()
