@@ -86,7 +86,7 @@ constexpr int kProbeSlots = 65536;
 __device__ unsigned long long g_probe[kProbeSlots * 8];   // one record per workgroup (wave 0): no atomics in the timed path
 #endif
 
-template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
+template <typename T, int BM, int BN, int MR, int NR, int NSTAGE, int HALO = 0>
 __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gconv_kernel(const GDesc d, const T* __restrict__ in, const T* __restrict__ wp,
                                                     const float* __restrict__ bias,
                                                     const typename OutOf<T>::type* __restrict__ addend,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   extern __shared__ float4 smem_raw[];
   char* smem = reinterpret_cast<char*>(smem_raw);
   int* tab = reinterpret_cast<int*>(smem);                    // [T_taps][BM] gathered input pixel (or -1)
-  int2* rinfo = reinterpret_cast<int2*>(smem + ((T_taps * BM * 4 + 15) & ~15));   // [BM] {sample or -1, ho << 16 | wo}
+  int2* rinfo = reinterpret_cast<int2*>(smem + (HALO ? 0 : ((T_taps * BM * 4 + 15) & ~15)));   // [BM] {sample or -1, ho << 16 | wo}  (HALO: no gather table)
   char* stages = reinterpret_cast<char*>(rinfo + BM);
 #ifdef P2PHD_PROBE
   const unsigned long long pr_t0 = __builtin_readcyclecounter();
@@ -144,6 +144,24 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const int p_end = flat ? d.N * npix : npix;                 // rows >= p_end are padding
   const int n0 = by * BN;
 
+  f32x16 acc[MR][NR];
+#pragma unroll
+  for (int i = 0; i < MR; ++i)
+#pragma unroll
+    for (int j = 0; j < NR; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+#ifdef P2PHD_PROBE
+  unsigned long long pr_t1_ = 0, pr_wait_ = 0, pr_bar_ = 0, pr_comp_ = 0;
+  int nsteps_ = 0;
+#ifdef P2PHD_PROBE_FINE
+  unsigned long long pf_a = 0, pf_b = 0;
+#endif
+#endif
+  if constexpr (HALO != 0) {
+#include "gconv_halo.inc"
+  } else {
   {  // row table (the only integer divisions of the kernel: one or two per tile row), then the gather table
     // input pixel index (or -1) per (tap, tile row): each thread walks its row's taps with counters
     const int Hin = d.Hin, Win = d.Win, sh = d.sh, sw = d.sw, ntw = d.ntw, pad_mode = d.pad_mode;
@@ -195,7 +213,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   }
   __syncthreads();
 #ifdef P2PHD_PROBE_FINE
-  const unsigned long long pf_a = __builtin_readcyclecounter();
+  pf_a = __builtin_readcyclecounter();
 #endif
 
   // Direct global -> LDS staging (buffer_load_dwordx4 ... lds): one wave instruction fills 8 consecutive 128-byte
@@ -261,6 +279,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   // piece j of a tile: 0..NA-1 = A rows rbase + RS j, NA.. = B rows; tile = K-slab index (scalar offset of B)
   auto issue_piece = [&](int slot, int tile, int j) {
     char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
+#ifdef P2PHD_ABL_ADMA1
+    if (j >= 1 && j < NA) return;                              // experiment: one A piece per thread and slab (what an LDS halo would issue)
+#endif
     if (j < NA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(A + RS * j * kRowBytes), 16, (int)va[j], 0, 0, 0);
     } else {
@@ -270,15 +291,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     }
   };
 
-  f32x16 acc[MR][NR];
-#pragma unroll
-  for (int i = 0; i < MR; ++i)
-#pragma unroll
-    for (int j = 0; j < NR; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int lr = lane & 31, lh = lane >> 5;
   // Fragment reads are inline-asm ds_read_b128: hipcc cannot prove a C++ LDS read independent of the LDS-DMA still in
   // flight and would drain it (s_waitcnt vmcnt(0)) in front of every K step; the waits here are counted by hand.
   // byte offset inside a stage of the fragment of k-step ks: row * 128 + (((2 ks + lh) ^ ((row >> 1) & 7)) << 4)
@@ -393,7 +405,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     }
   }
 #ifdef P2PHD_PROBE_FINE
-  const unsigned long long pf_b = __builtin_readcyclecounter();
+  pf_b = __builtin_readcyclecounter();
 #endif
   if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -479,6 +491,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
     for (int p = 0; p < H1; ++p) mfma8(0, p);
   }
+#ifdef P2PHD_PROBE
+  pr_t1_ = pr_t1; pr_wait_ = pr_wait; pr_bar_ = pr_bar; pr_comp_ = pr_comp; nsteps_ = nsteps;
+#endif
+  }  // !HALO
 #ifdef P2PHD_PROBE
   const unsigned long long pr_t2 = __builtin_readcyclecounter();
 #endif
@@ -782,11 +798,11 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_PROBE_FINE
     // prologue: table build | descriptor + fragment addresses + DMA issue | first wait + barrier + first fragments;
     // epilogue: statistics + LDS staging | barrier | store loop (the barrier after the K loop is in the first)
-    r[0] += pf_a - pr_t0; r[1] += pf_b - pf_a; r[2] += pr_t1 - pf_b; r[3] += pr_t2 - pr_t1;
+    r[0] += pf_a - pr_t0; r[1] += pf_b - pf_a; r[2] += pr_t1_ - pf_b; r[3] += pr_t2 - pr_t1_;
     r[4] += pf_c - pr_t2; r[5] += pf_d - pf_c; r[6] += 1ull; r[7] += pr_t3 - pf_d;
 #else
-    r[0] += pr_wait; r[1] += pr_bar; r[2] += pr_comp; r[3] += (unsigned long long)nsteps;
-    r[4] += pr_t1 - pr_t0; r[5] += pr_t3 - pr_t2; r[6] += 1ull; r[7] += pr_t3 - pr_t0;
+    r[0] += pr_wait_; r[1] += pr_bar_; r[2] += pr_comp_; r[3] += (unsigned long long)nsteps_;
+    r[4] += pr_t1_ - pr_t0; r[5] += pr_t3 - pr_t2; r[6] += 1ull; r[7] += pr_t3 - pr_t0;
 #endif
   }
 #endif
@@ -1779,7 +1795,7 @@ struct GconvProbe {
 };
 GconvProbe g_probe_cfg;
 
-template <typename T, int BM, int BN, int MR, int NR, int NSTAGE>
+template <typename T, int BM, int BN, int MR, int NR, int NSTAGE, int HALO = 0>
 int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const float* bias, const void* addend, void* out,
                      float* stats, hipStream_t st, int* slot_rows) {
   GDesc d = d_in;
@@ -1788,9 +1804,10 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   if (slot_rows) *slot_rows = d.bs_out != nullptr ? BM : MR * 32;   // (fused backward sums: one partial per TILE)
   constexpr int STAGE = (BM + BN) * kRowBytes;
   constexpr int CT = BM * (BN * (int)sizeof(typename OutOf<T>::type) + 16);
-  const int tab = ((d.nth * d.ntw * BM * 4 + 15) & ~15) + BM * 8;        // gather table + row table
-  const size_t lds = tab + (size_t)(NSTAGE * STAGE > CT ? NSTAGE * STAGE : CT);
-  auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE>;
+  const int tab = (HALO ? 0 : ((d.nth * d.ntw * BM * 4 + 15) & ~15)) + BM * 8;        // gather table + row table
+  constexpr int RING = HALO ? 2 * (20 * 20 * kRowBytes) + 2 * BN * kRowBytes : NSTAGE * STAGE;   // (HALO: two halo grids + two weight slabs, gconv_halo.inc)
+  const size_t lds = tab + (size_t)(RING > CT ? RING : CT);
+  auto kern = gconv_kernel<T, BM, BN, MR, NR, NSTAGE, HALO>;
   if (lds > 64 * 1024)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int npix = d.Hg * d.Wg;
@@ -1808,7 +1825,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   // CUs this launch can occupy: the device's count (cached per device), or what the caller states with
   // p2phd_set_option("cus", n) when the step runs on a CU-masked stream (opt.comm_cus leaves some to the RCCL kernels)
   const int cus = p2phd::g_opt_cus > 0 ? p2phd::g_opt_cus : p2phd::device_cus();
-  if (p2phd::g_opt_splitk_tail != 0 && d.cls_skip == 0) {        // (tap-skipping tiles differ in depth: their order balances the rounds)
+  if (p2phd::g_opt_splitk_tail != 0 && d.cls_skip == 0 && HALO == 0) {        // (tap-skipping tiles differ in depth: their order balances the rounds)
     const int nsteps = d.KK / (8 * Elem<T>::EPP);
     const int full = TT / cus * cus, tail = TT - full;
     // Cost model in microseconds (layer tables of profiles/r03_*): a K slab of a BM x BN tile at the rate one CU sustains in
@@ -1854,6 +1871,17 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   hipLaunchKernelGGL(kern, grid, dim3((BM / (MR * 32)) * (BN / (NR * 32)) * 64), lds, st, d, (const T*)in, (const T*)wp, bias, (const TO*)addend, (TO*)out, stats);
   if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
+}
+
+// The HALO main loop of the 256 x 192 tile (gconv_halo.inc): 3 x 3 taps within one pixel of the centre on a 16-wide plane whose
+// height is a multiple of 16, gathered tensor of the same size, 64-channel chunks, full K rows (no padding tail)
+bool gconv_halo_ok(const GDesc& d) {
+  const bool taps = d.nth == 3 && d.ntw == 3 && d.sh == 1 && d.sw == 1 &&
+                    ((d.dh0 == -1 && d.dh_step == 1) || (d.dh0 == 1 && d.dh_step == -1)) &&
+                    ((d.dw0 == -1 && d.dw_step == 1) || (d.dw0 == 1 && d.dw_step == -1));
+  return p2phd::g_opt_gconv_halo != 0 && taps && d.cls_cp == 0 && d.Wg == 16 && d.Hg % 16 == 0 && d.Hg >= 16 && d.Hin == d.Hg && d.Win == d.Wg &&
+         d.Cp_in % 64 == 0 && d.KK == 9 * d.Cp_in && (d.pad_mode == 0 || d.pad_mode == 1 || d.pad_mode == 3) && d.flat_m == 0 &&
+         d.oh_mul == 1 && d.ow_mul == 1 && d.oh_off == 0 && d.ow_off == 0;
 }
 
 template <typename T>
@@ -1906,8 +1934,12 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   if ((huge || (sizeof(T) == 1 && wide)) && force == 0 && k % 192 == 0) {
     const long wg256 = mt256 * ((k + 255) / 256), wg192 = mt256 * (k / 192);
     const double c256 = std::ceil(wg256 / 256.0) * 256.0 * 256.0, c192 = std::ceil(wg192 / 256.0) * 256.0 * 192.0 / 0.95;
-    if ((sizeof(T) == 1 || c192 < c256) && 2 * 448 * kRowBytes + tabb <= kLds)
+    if ((sizeof(T) == 1 || c192 < c256) && 2 * 448 * kRowBytes + tabb <= kLds) {
+      if constexpr (sizeof(T) == 2) {
+        if (gconv_halo_ok(d)) return launch_gconv_cfg<T, 256, 192, 2, 3, 2, 1>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+      }
       return launch_gconv_cfg<T, 256, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+    }
   }
   // ... and for 192- / 384-wide outputs (the 96-channel layers and the merged sub-pixel launches of the up path),
   // where 128-wide tiles would gather the A operand once more and pad the last tile

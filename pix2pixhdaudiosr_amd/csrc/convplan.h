@@ -93,7 +93,7 @@ size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
-extern int g_opt_march; extern int g_opt_cls_skip;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
+extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);

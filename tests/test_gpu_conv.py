@@ -60,6 +60,12 @@ CASES = [
     ("skip_ct_192to96", 192, 96, 3, 2, 1, 0, True, 1, True, 3, (8, 64, 64), False),
     ("skip_ct_384to192", 384, 192, 3, 2, 1, 0, True, 1, True, 3, (4, 64, 64), False),
     ("skip_s2_96to192", 96, 192, 3, 2, 1, 0, False, 0, True, 3, (8, 128, 128), False),
+    # round 4: the HALO main loop of the 256 x 192 tile (csrc/gconv_halo.inc; 16-bit types, 16-wide planes, >= 160 tiles):
+    # forward behind ReflectionPad2d(1) (768 output channels: the tile's GEMM N), and the input gradient through the reflection
+    # adjoint's extras (768 INPUT channels), two 64-channel chunks of K each; the 48-row plane has a tile with neither border
+    ("halo_fwd_128to768", 128, 768, 3, 1, 1, 1, False, 0, True, 3, (28, 32, 16), False),
+    ("halo_dgrad_768to128", 768, 128, 3, 1, 1, 1, False, 0, True, 3, (28, 32, 16), False),
+    ("halo_both_768_rows48", 768, 768, 3, 1, 1, 1, False, 0, True, 3, (19, 48, 16), False),
 ]
 
 
