@@ -163,6 +163,16 @@ def _bwd_range(n, paired=True):
     return None
 
 
+def _zero_unused(t, rng):
+    """The samples outside `rng` of a sample-range backward's result are never read by the Functions of the paired pass (they
+    are restricted to the same range; ToPhysicalPair.backward reads the fake half only) and are left unwritten: 0.5 GB of
+    memsets per step would buy nothing.  Anything that LOOKS at whole gradients -- anomaly mode, or a hook / retain_grad a
+    user announces with P2PHD_ZERO_UNUSED=1 -- gets zeros there instead of stale memory."""
+    if torch.is_anomaly_enabled() or os.environ.get("P2PHD_ZERO_UNUSED", "0") == "1":
+        t[:rng[0]].zero_()
+        t[rng[1]:].zero_()
+
+
 def _is_pair(t):
     return bool(getattr(t, "_p2phd_pair", False))
 
@@ -717,6 +727,8 @@ class ConvBlockFn(torch.autograd.Function):
             wp = spec.packed(weight, 1, d)
             gx_full = empty_like(x_full)
             gx = gx_full if rng is None else gx_full[rng[0]:rng[1]]
+            if rng is not None:
+                _zero_unused(gx_full, rng)
             wsb = L.p2phd_conv_dgrad_workspace_bytes(C.byref(d))
             ws = workspace(wsb, y.device) if wsb else None
             # first conv of a residual block: the skip gradient parked by the block's second conv is added inside the
@@ -864,6 +876,7 @@ class AvgPoolFn(torch.autograd.Function):
         rng = _bwd_range(N, ctx.pair)
         if rng is not None:                                        # sample-range backward (backward_on_samples)
             lo, hi = rng
+            _zero_unused(dx, rng)
             check(lib_for(g.dtype).p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g[lo:hi]), ptr(dx[lo:hi]), hi - lo, H, W, channels, stream_ptr()), "avgpool_bwd")
         else:
             check(lib_for(g.dtype).p2phd_avgpool3s2_bwd(dt_code(g.dtype), ptr(g), ptr(dx), N, H, W, channels, stream_ptr()), "avgpool_bwd")

@@ -1021,6 +1021,12 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
   // piece j of a tile: 0..3 gather panels, 4.. rows-operand panels
   auto issue_piece = [&](int slot_, int j) {
     char* A = smem + slot_ * STAGE;
+#ifdef P2PHD_ABL_WGRAD_GDMA1
+    if (j >= 1 && j < PPT) return;                               // experiment: one gather piece per thread and step
+#endif
+#ifdef P2PHD_ABL_WGRAD_ADMA1
+    if (j >= PPT + 1) return;                                    // experiment: one rows-operand piece per thread and step
+#endif
     if (j < PPT) {
       char* G = A + TILEA + (grp * PPT + j) * PANEL + wrow8 * 128;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)G, 16, (int)vG[j], 0, 0, 0);

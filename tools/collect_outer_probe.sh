@@ -1,10 +1,13 @@
 #!/usr/bin/env bash
-# Round-3 evidence for DESIGN §6 "Where a short-K tile's cycles go" (run through gpurun after
-#   tools/ablate_gconv.sh probe "-DP2PHD_PROBE" probefine "-DP2PHD_PROBE -DP2PHD_PROBE_FINE -DP2PHD_PROBE_DRAIN"
-# with pix2pixhdaudiosr_amd/abl/ not git/gpurun-ignored).  Writes gpurun_out/outer/probe.log.
+# Round-3 evidence for DESIGN section 6 "Where a short-K tile's cycles go" (run through gpurun).  The probe builds of the library
+# live in pix2pixhdaudiosr_amd/abl/, which .gpurunignore keeps out of the snapshot (experiment binaries do not ship): the
+# script therefore BUILDS them on the GPU box first (hipcc is there; about two minutes).  Writes gpurun_out/outer/probe.log.
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}"
 mkdir -p gpurun_out/outer
+if [ ! -f pix2pixhdaudiosr_amd/abl/libp2phd_probe.so ] || [ ! -f pix2pixhdaudiosr_amd/abl/libp2phd_probefine.so ]; then
+  bash tools/ablate_gconv.sh probe "-DP2PHD_PROBE" probefine "-DP2PHD_PROBE -DP2PHD_PROBE_FINE -DP2PHD_PROBE_DRAIN" > gpurun_out/outer/build.log 2>&1
+fi
 LOG=gpurun_out/outer/probe.log
 : > $LOG
 A="48 96 512 256 2 0"

@@ -37,8 +37,9 @@ def pmc(paths, out):
     json.dump(res, open(out, "w"), indent=1)
     print("wrote", out)
 
-LABELS = (("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2", "gconv_kernel<bf16,256,192,2,3,2> trunk Conv3x3 768->768 @32x16 B=32 forward"),
-          ("gconv_kernelIDF16bLi256ELi256ELi4ELi2ELi2", "gconv_kernel<bf16,256,256,4,2,2> discriminator Conv4x4 256->512 @65x33 B=32 forward"),
+LABELS = (("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2ELi1", "gconv_kernel<bf16,256,192,2,3,2,HALO> trunk Conv3x3 768->768 @32x16 B=32 forward"),
+          ("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2ELi0", "gconv_kernel<bf16,256,192,2,3,2> (generic loop) trunk Conv3x3 768->768 @32x16 B=32 forward"),
+          ("gconv_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi0", "gconv_kernel<bf16,256,256,4,2,2> discriminator Conv4x4 256->512 @65x33 B=32 forward"),
           ("wgrad_kernelIDF16bLi256", "wgrad_kernel<bf16,256> trunk weight gradient 768x6912, 16384 pixels"),
           ("march_s_kernel<48, 96, 64, false>", "march_s_kernel<48,96,64> Conv3x3 s2 48->96 @512x256 B=32 forward (marching, round 4)"),
           ("march_u_kernel<96, 48, 64, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"))
@@ -141,8 +142,8 @@ def one_step(path, out):
     def fam(n):
         n = short(n).replace("void ", "")
         n = re.sub(r"^\d+", "", n)
-        m = re.match(r"gconv_kernelI(DF16b|f|NS_5fp8_tE)Li(\d+)ELi(\d+)", n)
-        if m: return f"gconv_kernel<{m.group(2)}x{m.group(3)}>"
+        m = re.match(r"gconv_kernelI(DF16b|f|NS_5fp8_tE)Li(\d+)ELi(\d+)(?:ELi\d+ELi\d+ELi\d+ELi(\d+)E)?", n)
+        if m: return f"gconv_kernel<{m.group(2)}x{m.group(3)}{' halo' if m.group(4) == '1' else ''}>"
         m = re.match(r"wgrad_kernelI(DF16b|f)Li(\d+)", n)
         if m: return f"wgrad_kernel<{m.group(2)}>"
         return re.sub(r"\(.*", "", re.sub(r"<.*", "", re.sub(r"I(DF16b|f).*", "", n)))[:44]
