@@ -40,6 +40,12 @@ def layer(name, count, cin, cout, k, stride, pad, pad_mode, transposed, opad, H,
     bytes_fwd = (x.numel() + y.numel()) * esz
     f = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp0), None, 0, _ops.ptr(y), _ops.ptr(stats if norm else None), _ops.ptr(ws), _ops.stream_ptr()))
     g = lambda: _ops.check(L.p2phd_conv_dgrad(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), None, _ops.ptr(gx), _ops.ptr(ws), _ops.stream_ptr()))
+    n_rx = L.p2phd_conv_reflect_extras_elems(C.byref(d)) if (pad_mode == 1 and norm) else 0
+    if n_rx:
+        # as in the step (round 4): the gradient comes out of the single-launch InstanceNorm backward with the reflection
+        # extras behind it, the input gradient reads them in place (timing only: the extras hold random values here)
+        dyx = torch.randn(dy.numel() + n_rx, device="cuda").to(dt)
+        g = lambda: _ops.check(L.p2phd_conv_dgrad_rx(C.byref(d), _ops.ptr(dyx), _ops.ptr(wp1), None, _ops.ptr(gx), _ops.stream_ptr()))
     h = lambda: _ops.check(L.p2phd_conv_wgrad(C.byref(d), _ops.ptr(x), _ops.ptr(dy), _ops.ptr(gw), None, _ops.ptr(ws), _ops.stream_ptr()))
     tf = timeit(f); tg = timeit(g) if need_dgrad else 0.0; th = timeit(h)
     def fmt(t): return f"{t*1e6:7.0f}us {flops/t/1e12:5.0f}TF {bytes_fwd/t/1e12:4.1f}TB/s" if t > 0 else " " * 27

@@ -41,8 +41,8 @@ LABELS = (("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2ELi1", "gconv_kernel<bf16,2
           ("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2ELi0", "gconv_kernel<bf16,256,192,2,3,2> (generic loop) trunk Conv3x3 768->768 @32x16 B=32 forward"),
           ("gconv_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi0", "gconv_kernel<bf16,256,256,4,2,2> discriminator Conv4x4 256->512 @65x33 B=32 forward"),
           ("wgrad_kernelIDF16bLi256", "wgrad_kernel<bf16,256> trunk weight gradient 768x6912, 16384 pixels"),
-          ("march_s_kernel<48, 96, 64, false>", "march_s_kernel<48,96,64> Conv3x3 s2 48->96 @512x256 B=32 forward (marching, round 4)"),
-          ("march_u_kernel<96, 48, 64, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"))
+          ("march_s_kernel<48, 96, 64, false, false>", "march_s_kernel<48,96,64> Conv3x3 s2 48->96 @512x256 B=32 forward (marching, round 4)"),
+          ("march_u_kernel<96, 48, 64, false, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"))
 
 
 def derive(paths, out, trunk_out):
@@ -123,6 +123,10 @@ def traffic(fetch_csv, write_csv, steps, out):
                 "| kernel | launches/step | read GB/step | written GB/step | time ms/step |\n|---|---|---|---|---|\n")
         for k, v in rows[:40]:
             f.write(f"| `{k[-70:]}` | {v[0] / steps:.1f} | {2 * v[1] * 1024 / steps / 1e9:.2f} | {v[2] * 1024 / steps / 1e9:.2f} | {v[3] / steps / 1e6:.2f} |\n")
+        fill = sum(v[2] for k, v in acc.items() if "FillFunctor<float>" in k) * 1024 / 1e9
+        f.write(f"\nNot step work: the `FillFunctor<float>` row is the optimisers' zero-initialisation of their flat parameter / gradient / "
+                f"moment buffers when the model is built ({fill:.2f} GB once per process, shown here divided by the {steps} step-equivalents); "
+                "the step itself zeroes no gradient buffer (lazy `zero_grad`: the first weight gradient overwrites, optim.py).\n")
     print("wrote", out, f"read {tot_r:.1f} GB written {tot_w:.1f} GB per step")
 
 
