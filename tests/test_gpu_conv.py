@@ -570,6 +570,61 @@ def test_reflection_extras_written_by_the_instancenorm_backward(geom, dtype, tol
         assert rel_err(outs[0][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(outs[0][2].numpy(), go[1].numpy()) < 3e-4
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("geom", [(32, 32, 768), (56, 16, 768), (10, 96, 768)], ids=["trunk_32x16x768", "16rows", "96rows_forward_only"])
+def test_halo_loop_equals_the_generic_loop(geom, dtype):
+    """Round 4: the HALO main loop of the 256 x 192 tile (csrc/gconv_halo.inc, option gconv_halo) against the generic loop
+    on the same launches -- the residual-trunk layer at its real size, forward (ReflectionPad2d(1) gather) with statistics
+    and input gradient through the reflection extras --, on a 16-row plane (one tile holds both borders) and, forward only, on a
+    96-row plane (tiles with no image border; planes above 640 pixels take the two-pass InstanceNorm backward, which has no extras).
+    The two loops add the same products in a different order (chunk-tap-channel against tap-channel): outputs agree to
+    the rounding of the 16-bit store, the fp32 statistics to accumulation noise."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _ops.lib_for(dtype)
+    N, H, CH = geom
+    W = 16
+    gen = torch.Generator().manual_seed(H + CH)
+    spec = _ops.ConvSpec(CH, CH, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, dtype)
+    x = torch.randn(N, H, W, CH, generator=gen).cuda().to(dtype)
+    w = (torch.randn(CH, CH, 3, 3, generator=gen) * 0.02).cuda()
+    g = torch.randn(N, H, W, CH, generator=gen).cuda().to(dtype)
+    y = torch.empty_like(x); gx = torch.empty_like(x)
+    stats = torch.zeros(N, CH, 2, device="cuda")
+    wp0, wp1 = spec.packed(w, 0, d), spec.packed(w, 1, d)
+    ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 1 << 20), "cuda")
+    n_rx = L.p2phd_conv_reflect_extras_elems(C.byref(d))
+    assert n_rx == (N * (2 * (W + 2) + 2 * H) * CH if H * W <= 640 else 0)
+    if n_rx:
+        buf = torch.empty(x.numel() + n_rx, device="cuda", dtype=dtype)
+        dy, rx = buf[:x.numel()].view(x.shape), buf[x.numel():]
+        st = torch.zeros(N, CH, 2, device="cuda"); st[..., 1] = H * W
+        db = torch.zeros(CH, device="cuda")
+        _ops.check(L.p2phd_instnorm_act_bwd_rx(d.dtype, _ops.ptr(g), _ops.ptr(x), _ops.ptr(st), _ops.ptr(dy), _ops.ptr(db), 1, N, H, W, CH, 1e-5,
+                                               _ops.ACT_RELU, _ops.ptr(rx), _ops.stream_ptr()))
+    res = {}
+    try:
+        for halo in (0, 1):
+            _lib.check(L.p2phd_set_option(b"gconv_halo", halo))
+            _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp0), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
+            if n_rx:
+                _ops.check(L.p2phd_conv_dgrad_rx(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), None, _ops.ptr(gx), _ops.stream_ptr()))
+            else:
+                gx.copy_(y)
+            torch.cuda.synchronize()
+            res[halo] = (y.float().cpu().numpy(), stats.cpu().numpy().copy(), gx.float().cpu().numpy())
+    finally:
+        _lib.check(L.p2phd_set_option(b"gconv_halo", 1))
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert rel_err(res[1][0], res[0][0]) < ulp and rel_err(res[1][2], res[0][2]) < ulp
+    assert np.abs(res[1][0] - res[0][0]).max() <= 2 * ulp * np.abs(res[0][0]).max()
+    assert np.abs(res[1][2] - res[0][2]).max() <= 2 * ulp * np.abs(res[0][2]).max()
+    assert rel_err(res[1][1], res[0][1]) < 1e-5                      # (mean, M2) per sample and channel, fp32
+    assert not np.array_equal(res[1][1], res[0][1])                  # ... and not the same bits: the other loop really ran
+    assert float(np.linalg.norm(res[0][0])) > 0 and float(np.linalg.norm(res[0][2])) > 0
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
 def test_activation_backward_fused_into_the_consumers_dgrad(dtype, tol, monkeypatch):
     """Producer without InstanceNorm (Conv + LeakyReLU, the discriminator's first layer): the exclusive consumer's
