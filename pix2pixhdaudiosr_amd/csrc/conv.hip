@@ -1080,6 +1080,24 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     P2PHD_TR_READ(hi, addr, 16 * (SUB) * (PITCH) + 4 * (PITCH));                                       \
   } while (0)
     auto read_frags = [&](unsigned so, int sub, int buf) {
+#if defined(P2PHD_ABL_WGRAD_B128A) || defined(P2PHD_ABL_WGRAD_B128AG)
+      // experiment (timing only, wrong numbers): the rows operand's fragments as ONE ds_read_b128 each instead of two transposing reads
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        uint4 v4;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v4) : "v"((so + ta_off[i] + (unsigned)(sub * 2048)) & ~15u));
+        af[buf][i][0] = make_uint2(v4.x, v4.y); af[buf][i][1] = make_uint2(v4.z, v4.w);
+      }
+#ifdef P2PHD_ABL_WGRAD_B128AG
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        uint4 v4;
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v4) : "v"((so + tg_off[j] + (unsigned)(sub * 2048)) & ~15u));
+        gf[buf][j][0] = make_uint2(v4.x, v4.y); gf[buf][j][1] = make_uint2(v4.z, v4.w);
+      }
+      return;
+#endif
+#else
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const unsigned ad = so + ta_off[i];
@@ -1090,6 +1108,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
           default: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 3, RPA); break;
         }
       }
+#endif
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const unsigned ad = so + tg_off[j];
@@ -1255,7 +1274,14 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row_o = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+#ifdef P2PHD_ABL_WGRAD_NOSTORE
+        if (acc[i][j][e] == 123456.f)                              // experiment: no slab stores (timing only)
+#endif
+#ifdef P2PHD_ABL_WGRAD_NTSTORE
+        __builtin_nontemporal_store(acc[i][j][e], &slab[(size_t)row_o * KK + col]);
+#else
         slab[(size_t)row_o * KK + col] = acc[i][j][e];
+#endif
       }
     }
 }
