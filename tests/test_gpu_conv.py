@@ -614,6 +614,14 @@ def test_halo_loop_equals_the_generic_loop(geom, dtype):
                 gx.copy_(y)
             torch.cuda.synchronize()
             res[halo] = (y.float().cpu().numpy(), stats.cpu().numpy().copy(), gx.float().cpu().numpy())
+        # the HALO loop counts its LDS-DMA waits by hand: 200 more launches of each must reproduce the first bit for bit (the
+        # stale-fragment race this test once caught showed up in one launch of a few hundred: -DP2PHD_ABL_HALO_RACE brings it back)
+        y0, g0, s0 = y.clone(), gx.clone(), stats.clone()
+        for _ in range(200):
+            _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp0), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
+            if n_rx:
+                _ops.check(L.p2phd_conv_dgrad_rx(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), None, _ops.ptr(gx), _ops.stream_ptr()))
+            assert torch.equal(y, y0) and torch.equal(stats, s0) and (not n_rx or torch.equal(gx, g0))
     finally:
         _lib.check(L.p2phd_set_option(b"gconv_halo", 1))
     ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
