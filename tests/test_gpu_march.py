@@ -118,3 +118,54 @@ def test_lazily_normalised_input_equals_the_materialised_form(kind):
     assert torch.equal(o, o2)
     with pytest.raises(Exception):
         _ops.FromPhysical.apply(h, specP.cout)                      # a raw tensor must not leave the chain
+
+
+@pytest.mark.parametrize("kind", ["conv", "convT"])
+def test_marching_kernels_reproduce_their_results_launch_after_launch(kind):
+    """The marching kernels hand rows from wave to wave through LDS rings with one barrier per step and hand-placed waits: 100
+    repeats of every launch form (forward, input gradient with and without the fused InstanceNorm-backward sums, weight
+    gradient, and the lazily normalising forward / weight gradient) must reproduce the first launch bit for bit -- a race in
+    the ring shows up as one differing launch in a few hundred (cf. test_halo_loop_equals_the_generic_loop)."""
+    from pix2pixhdaudiosr_amd import _ops
+    L = _ops.lib()
+    dt = torch.bfloat16
+    B = 8
+    if kind == "conv":
+        cin, cout, transposed, H, W = 48, 96, False, 128, 256
+    else:
+        cin, cout, transposed, H, W = 96, 48, True, 64, 128
+    gen = torch.Generator().manual_seed(7)
+    spec = _ops.ConvSpec(cin, cout, 3, 2, 1, 0, transposed, 1 if transposed else 0, True, 0)
+    d = spec.desc(B, H, W, dt)
+    Ho, Wo = spec.out_size(d)
+    x = torch.randn(B, H, W, _ops.cpitch(cin), generator=gen).cuda().to(dt)
+    w = (torch.randn((cin, cout, 3, 3) if transposed else (cout, cin, 3, 3), generator=gen) * 0.05).cuda()
+    dy = torch.randn(B, Ho, Wo, _ops.cpitch(cout), generator=gen).cuda().to(dt)
+    y = torch.empty_like(dy); gx = torch.empty_like(x); gw = torch.empty_like(w)
+    stats = torch.zeros(B, _ops.cpitch(cout), 2, device="cuda")
+    prev_stats = torch.zeros(B, _ops.cpitch(cin), 2, device="cuda"); prev_stats[..., 1] = H * W
+    bst = torch.empty(B, _ops.cpitch(cin), 2, device="cuda")
+    wp0, wp1 = spec.packed(w, 0, d), spec.packed(w, 1, d)
+    ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), L.p2phd_conv_dgrad_workspace_bytes(C.byref(d)),
+                            L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), L.p2phd_conv_wgrad_workspace_bytes(C.byref(d)), 1 << 20), "cuda")
+    P, S = _ops.ptr, _ops.stream_ptr
+    forms = {
+        "fwd": (lambda: L.p2phd_conv_fwd(C.byref(d), P(x), P(wp0), None, 0, P(y), P(stats), P(ws), S()), lambda: (y, stats)),
+        "dgrad": (lambda: L.p2phd_conv_dgrad(C.byref(d), P(dy), P(wp1), None, P(gx), P(ws), S()), lambda: (gx,)),
+        "dgrad+sums": (lambda: L.p2phd_conv_dgrad_bsum(C.byref(d), P(dy), P(wp1), None, P(gx), P(x), P(prev_stats), _ops.ACT_RELU, 1e-5, P(bst), P(ws), S()),
+                       lambda: (gx, bst)),
+        "wgrad": (lambda: L.p2phd_conv_wgrad(C.byref(d), P(x), P(dy), P(gw), None, P(ws), S()), lambda: (gw,)),
+        "fwd_lazy": (lambda: L.p2phd_conv_fwd_lazy(C.byref(d), P(x), P(prev_stats), _ops.ACT_RELU, 1e-5, P(wp0), None, P(y), P(stats), P(ws), S()),
+                     lambda: (y, stats)),
+        "wgrad_lazy": (lambda: L.p2phd_conv_wgrad_lazy(C.byref(d), P(x), P(prev_stats), _ops.ACT_RELU, 1e-5, P(dy), P(gw), None, 0, P(ws), S()),
+                       lambda: (gw,)),
+    }
+    assert L.p2phd_conv_lazy_ok(C.byref(d))
+    for name, (call, outs) in forms.items():
+        _ops.check(call(), name)
+        first = [t.clone() for t in outs()]
+        assert all(torch.isfinite(t.float()).all() for t in first), name
+        for rep in range(100):
+            _ops.check(call(), name)
+            for a, b in zip(outs(), first):
+                assert torch.equal(a, b), (name, rep)
