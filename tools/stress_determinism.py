@@ -5,7 +5,7 @@ carries signal compared bit for bit with the first run.  Every reduction on the 
 its waits counted by hand -- a miscounted wait shows up here as one differing run in a few hundred launches
 (tests/test_gpu_conv.py::test_halo_loop_equals_the_generic_loop found one that way).
 
-    python tools/stress_determinism.py [N = 40]            (GPU)  ->  profiles/r04_determinism_stress.log
+    [FP16=1] python tools/stress_determinism.py [N = 40]            (GPU)  ->  profiles/r04_determinism_stress.log
 """
 import os
 import sys
@@ -21,7 +21,7 @@ from pix2pixhdaudiosr_amd.models.models import create_model  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 B = int(os.environ.get("B", "32"))
 torch.manual_seed(1234)
-opt = make_opt(B)
+opt = make_opt(B, fp16_storage=os.environ.get("FP16") == "1")       # FP16=1: the fp16 build of the library (unscaled losses here)
 opt.mask = False                                                 # no random mask rows: identical inputs by construction
 m = create_model(opt)
 gen = torch.Generator().manual_seed(5)
