@@ -393,6 +393,8 @@ def main():
                            (exch["G"]["host_wait_ms"] + exch["D"]["host_wait_ms"]) / a.steps], device="cuda", dtype=torch.float64)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
         gb = [int(b - a) for a, b in model.optimizer_G.bucket_log]
+        torch.cuda.synchronize()
+        spread = parallel_state.replica_checksum_spread(model)      # collective: every rank calls it
         dist_info = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rehearsal_one_rank": rehearse,
                      "g_gradient_buckets": gb,
                      "bucket_bytes": {"G": [(2 if a.wire_bf16 else 4) * n for n in gb], "D": [4 * int(model.optimizer_D._total)]},
@@ -403,6 +405,9 @@ def main():
                      "exposed_how": "HIP events on the compute stream around every wait for a collective (optim.FlatAdam.wait_gradients): "
                                     "the G buckets are waited for after the D backward, the D bucket after the generator's Adam",
                      "comm_cus": a.comm_cus,
+                     # max - min over the ranks of a 64-bit checksum of the master weights after the timed steps: 0 = the
+                     # replicas are still bit-identical (a missed / early-read exchange would show here, not in the speed)
+                     "replica_checksum_spread": spread,
                      "devices": sorted({local}) if "P2PHD_FORCE_DEVICE" in os.environ else list(range(world))}
 
     if rank == 0:

@@ -19,10 +19,11 @@
  * Streams
  *   The kernels that reduce across workgroups without float atomics (InstanceNorm backward sums, bias column sums, loss
  *   accumulators, the split-K tail of the conv GEMM) keep their partial rows and arrival tickets in a scratch that belongs
- *   to the library, one region per kernel family.  A region serves ONE stream at a time: entry points remember the last
- *   stream that used each region, and a call that arrives on another stream while that stream still has work in flight
- *   returns P2PHD_EINVAL (p2phd_last_error names the region) instead of mixing partials.  Order the streams first (event
- *   wait, synchronisation, graph capture boundary), or keep one compute stream per process.  p2phd_reduction_reset(stream)
+ *   to the library, one region per kernel family.  A region serves ONE stream at a time: every such launch records an event
+ *   behind itself, and a call of the same family that arrives on another stream first makes that stream wait for the event
+ *   (hipStreamWaitEvent) -- the launches are ordered on the device, no partials mix, nothing is refused and no stream handle
+ *   is ever queried after its owner may have destroyed it.  Launches recorded into a graph under capture run in graph order;
+ *   replaying two graphs that use one family concurrently on two streams is the caller's to order.  p2phd_reduction_reset(stream)
  *   re-arms the tickets; call it once per training step (a faulted or aborted launch could otherwise leave one armed wrong).
  */
 #ifndef P2PHD_H
@@ -66,6 +67,13 @@ int p2phd_probe_gconv(int enable, int cin_pitch, int kk, int hg, int wg);
  * (1 e4m3, 2 bf16, 4 f32; 0 = any) -- so a forward launch is told from the same-shaped input-gradient launch. */
 int p2phd_probe_gconv_ex(int enable, int cin_pitch, int kk, int hg, int wg, int gather_pad_mode, int elem_bytes);
 int p2phd_probe_read(float* ms_out, int cap);
+/* Launch counters: how many launches of a kernel family the library has made since the last reset -- "gconv" (every
+ * gather-GEMM launch), "halo" (those on the patch-staged 3x3 main loop), "cls_skip" (tap-skipping merged stride-2 launches),
+ * "splitk" (launches with a split-K tail), "tile256" (256 x 256 tiles), "patch" (the patch-staged 4x4 discriminator loop),
+ * "march" / "march_w" (marching kernels), "wgrad" (MFMA weight gradient).  family == NULL with reset != 0 clears all.
+ * Returns the count before the reset, -1 for an unknown name.  Counts launches recorded under graph capture once (at capture).
+ * Test hook: proves which kernels a whole training step really runs on (train.py:148-184 at the benchmarked batch). */
+int64_t p2phd_launch_count(const char* family, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * MDCT4 / IMDCT4 (models/mdct.py:461-566).  n_fft a power of two in [16, 4096].
@@ -159,6 +167,12 @@ int p2phd_conv_out_size(const p2phd_conv_desc* c, int* Ho, int* Wo);
  * (which = 1) launches; repack after every optimizer step. */
 size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which);
 int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w, void* packed, void* stream);
+/* Variant id (>= 0; -1: bad descriptor) of the packed layout that the launches of (desc, which) read.  The layout depends on
+ * more than the layer: a tap-skipping merged stride-2 launch orders the taps of half its sub-pixel classes differently, and
+ * whether a launch skips depends on N, H, W and the "cls_skip" option.  A buffer packed for one desc serves another desc of
+ * the same layer only if both report the same id -- a caller that caches packed weights keys the cache on it
+ * (the reference runs inference on a smaller last batch between training steps: train.py:206 -> eval_model). */
+int p2phd_conv_pack_layout(const p2phd_conv_desc* c, int which);
 
 /* y = act(conv(x) + bias).  If stats != NULL (float [N][Cp_out][2], overwritten; act must be NONE) it receives, per
  * (n, channel), the MEAN and the SUM OF SQUARED DEVIATIONS from it of conv(x)+bias over the sample's plane -- what

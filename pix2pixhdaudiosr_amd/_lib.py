@@ -29,6 +29,7 @@ SIGNATURES = {
     "p2phd_probe_gconv": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_gconv_ex": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_read": (_i32, [_vp, _i32]),
+    "p2phd_launch_count": (_i64, [C.c_char_p, _i32]),
     "p2phd_mdct4_tables_floats": (C.c_size_t, [_i32]),
     "p2phd_mdct4_tables_fill": (_i32, [_i32, _vp]),
     "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
@@ -43,6 +44,7 @@ SIGNATURES = {
     "p2phd_conv_kmajor_ok": (_i32, [_vp]),
     "p2phd_conv_packed_bytes": (C.c_size_t, [_vp, _i32]),
     "p2phd_conv_pack_weights": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "p2phd_conv_pack_layout": (_i32, [_vp, _i32]),
     "p2phd_conv_fwd_workspace_bytes": (C.c_size_t, [_vp]),
     "p2phd_conv_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "p2phd_conv_fp8_eligible": (_i32, [_vp]),
@@ -109,6 +111,7 @@ class ConvDesc(C.Structure):
 
 _libs = {}
 _last = [None]            # the library the latest call went to (p2phd_last_error is per library)
+_process_options = {}     # options set through set_option_all: every library of the process holds its own copy of them
 
 
 class P2PHDError(RuntimeError):
@@ -133,7 +136,22 @@ def _load(path, want_half):
         name, _, value = item.partition("=")
         if l.p2phd_set_option(name.strip().encode(), int(value)) != 0:
             raise P2PHDError(f"P2PHD_OPTIONS: {l.p2phd_last_error().decode()}")
+    for name, value in _process_options.items():                  # a library loaded late starts with the process's settings
+        if l.p2phd_set_option(name, value) != 0:
+            raise P2PHDError(f"set_option({name!r}): {l.p2phd_last_error().decode()}")
     return l
+
+
+def set_option_all(name, value):
+    """p2phd_set_option on EVERY library of the process (bf16 and fp16 builds keep separate option globals: a CU count or a
+    kernel switch set on one only would leave the other sizing its launches for the wrong machine), remembered for libraries
+    that are loaded later."""
+    if isinstance(name, str):
+        name = name.encode()
+    _process_options[name] = int(value)
+    for l in list(_libs.values()):
+        if l.p2phd_set_option(name, int(value)) != 0:
+            raise P2PHDError(f"set_option({name!r}): {l.p2phd_last_error().decode()}")
 
 
 def lib(kind="bf16"):

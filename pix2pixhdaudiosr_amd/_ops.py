@@ -452,7 +452,12 @@ class ConvSpec:
     def packed(self, weight, which, d):
         """Packed weights for forward (0) / input gradient (1); re-packed when the master copy changed.
         The dgrad pack of a stride-1 reflect conv depends on H, W only through the descriptor checks."""
-        key = (which, d.torch_dtype)
+        # the layout variant is part of the key: a tap-skipping launch (chosen from N, H, W and an option) reads another tap
+        # order than the plain one, so a pack made for the B = 32 training batch must not serve a smaller eval batch
+        layout = lib_for(d.torch_dtype).p2phd_conv_pack_layout(C.byref(d), which)
+        if layout < 0:
+            check(-1, "conv_pack_layout")
+        key = (which, d.torch_dtype, layout)
         stamp = (weight._version, weight.data_ptr(), _WEIGHT_EPOCH[0])
         hit = self._packed.get(key)
         if hit is not None and hit[0] == stamp:

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(256) void c7_out_fwd_kernel(const bf16_t* __restric
 
 namespace p2phd {
 
-bool c7_out_dgrad_ok(const p2phd_conv_desc* c) {
-  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+bool c7_out_dgrad_ok(const p2phd_conv_desc* c, bool ignore_option) {
+  return (ignore_option || !g_opt_c7_generic) && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
          c->pad == 3 && c->pad_mode == 1 && c->C % 16 == 0 && c->C >= 16 && c->C <= 128 && (c->C <= 64 || c->C % 32 == 0) &&
          c->H % TH == 0 && c->W % TW == 0 && c->H >= 8 && c->W >= 8;
 }
@@ -488,8 +488,8 @@ int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const
   return check_launch("c7_out_dgrad_fix");
 }
 
-bool c7_out_ok(const p2phd_conv_desc* c) {
-  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+bool c7_out_ok(const p2phd_conv_desc* c, bool ignore_option) {
+  return (ignore_option || !g_opt_c7_generic) && c->dtype == P2PHD_BF16 && !c->transposed && c->K == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
          c->pad == 3 && c->pad_mode == 1 && (c->C == 32 || c->C == 48 || c->C == 64 || c->C == 96 || c->C == 128) &&
          c->W % kStripW == 0 && c->H >= 8;
 }
@@ -519,8 +519,8 @@ int c7_out_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const fl
   return check_launch("c7_out_fwd");
 }
 
-bool c7_in_ok(const p2phd_conv_desc* c) {
-  return !g_opt_c7_generic && c->dtype == P2PHD_BF16 && !c->transposed && c->C == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
+bool c7_in_ok(const p2phd_conv_desc* c, bool ignore_option) {
+  return (ignore_option || !g_opt_c7_generic) && c->dtype == P2PHD_BF16 && !c->transposed && c->C == 2 && c->R == 7 && c->S == 7 && c->stride == 1 &&
          c->pad == 3 && c->pad_mode == 1 && c->K % 16 == 0 && c->K >= 16 && c->K <= 128 && (c->K <= 64 || c->K % 32 == 0) &&
          c->H % TH == 0 && c->W % TW == 0 && c->H > 3 && c->W > 3;
 }

@@ -9,8 +9,12 @@ namespace p2phd {
 
 void set_error(const char* fmt, ...);
 
+void fold_launched();   // core.hip: marks the launch that just went out as the latest user of the reduction-scratch region it took
+extern thread_local int g_fold_pending;   // region handed out by fold_scratch() and not yet launched on (-1: none)
+
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
+  if (g_fold_pending >= 0) fold_launched();
   if (e != hipSuccess) {
     set_error("%s: %s", what, hipGetErrorString(e));
     return P2PHD_ELAUNCH;
@@ -42,8 +46,9 @@ int imdct4_fast(const float* spec, int64_t B, int64_t n_frames, int n_fft, const
 // agent-scope integer atomic, and the workgroup that drew the last ticket sums the rows in index order -- the result
 // does not depend on which workgroup finishes when.  The scratch is a `__device__` array of the code object (no
 // allocation in any entry point); one region per kernel family, so the families may run on different streams, but two
-// launches of the SAME family must be ordered: fold_scratch() remembers the region's last stream and refuses a launch on
-// another stream while that one still has work in flight (P2PHD_EINVAL instead of mixed partials).
+// launches of the SAME family must be ordered: fold_scratch() remembers the region's last stream, the launch that follows
+// records the region's event behind itself (check_launch -> fold_launched), and a launch arriving on another stream first
+// makes that stream wait for the event -- the two launches are ordered on the device instead of mixing partials.
 enum FoldRegion { FOLD_IN_BWD = 0, FOLD_COLSUM = 1, FOLD_ACT_DB = 2, FOLD_LOSS = 3, FOLD_GCONV = 4 };
 struct FoldScratch { float* part; unsigned* ticket; size_t floats; int tickets; };
 FoldScratch fold_scratch(int region, hipStream_t stream);   // part == nullptr: refused (error text set), see core.hip

@@ -1901,6 +1901,11 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   if (probe) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, st); }
   typedef typename OutOf<T>::type TO;
   hipLaunchKernelGGL(kern, grid, dim3((BM / (MR * 32)) * (BN / (NR * 32)) * 64), lds, st, d, (const T*)in, (const T*)wp, bias, (const TO*)addend, (TO*)out, stats);
+  ++p2phd::g_launch_count[p2phd::LC_GCONV];
+  if (HALO != 0) ++p2phd::g_launch_count[p2phd::LC_HALO];
+  if (d.cls_skip != 0) ++p2phd::g_launch_count[p2phd::LC_CLS_SKIP];
+  if (d.sk_parts > 1) ++p2phd::g_launch_count[p2phd::LC_SPLITK];
+  if (BM == 256 && BN == 256) ++p2phd::g_launch_count[p2phd::LC_TILE256];
   if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
 }
@@ -2094,6 +2099,7 @@ void launch_wgrad_cfg(const GDesc& d, const void* rows, const void* gat, float* 
   auto kern = wgrad_kernel<T, TM>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   const int nx = (d.KK + 255) / 256, my = mrows / TM;
+  ++p2phd::g_launch_count[p2phd::LC_WGRAD];
   hipLaunchKernelGGL(kern, dim3((unsigned)(nx * my * splits)), dim3(512), lds, st, d, (const T*)rows, (const T*)gat, dwp, Cp_r, sps, slab_elems,
                      rows_bytes, nx, my, splits, p2phd::g_opt_wgrad_xcd);
 }

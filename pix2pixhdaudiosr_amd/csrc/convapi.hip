@@ -55,40 +55,12 @@ int check_desc(const p2phd_conv_desc* c) {
   return P2PHD_OK;
 }
 
-// shape test only (what the packed buffer must hold); whether a call takes the fast kernel also depends on the option
-bool c7_fast_shape(const p2phd_conv_desc* c) {
-  const int keep = g_opt_c7_generic;
-  g_opt_c7_generic = 0;
-  const bool ok = c7_in_ok(c);
-  g_opt_c7_generic = keep;
-  return ok;
-}
-
-bool c7_out_shape(const p2phd_conv_desc* c) {
-  const int keep = g_opt_c7_generic;
-  g_opt_c7_generic = 0;
-  const bool ok = c7_out_ok(c);
-  g_opt_c7_generic = keep;
-  return ok;
-}
-
-bool c7_dgrad_shape(const p2phd_conv_desc* c) {
-  const int keep = g_opt_c7_generic;
-  g_opt_c7_generic = 0;
-  const bool ok = c7_out_dgrad_ok(c);
-  g_opt_c7_generic = keep;
-  return ok;
-}
-
-// what the packed buffer must hold for march.hip, whatever the option says at the moment (the option can change between
-// the pack and the call; the buffer layout must not)
-size_t march_shape_elems(const p2phd_conv_desc* c, int which) {
-  const int keep = g_opt_march;
-  g_opt_march = 1;
-  const size_t n = march_packed_elems(c, which);
-  g_opt_march = keep;
-  return n;
-}
+// shape tests only (what the packed buffer must hold whatever the options say at the moment: an option can change between
+// the pack and the call, the buffer layout must not).  Pure functions: no global is touched (advisor, round 4).
+bool c7_fast_shape(const p2phd_conv_desc* c) { return c7_in_ok(c, true); }
+bool c7_out_shape(const p2phd_conv_desc* c) { return c7_out_ok(c, true); }
+bool c7_dgrad_shape(const p2phd_conv_desc* c) { return c7_out_dgrad_ok(c, true); }
+size_t march_shape_elems(const p2phd_conv_desc* c, int which) { return march_packed_elems(c, which); }
 size_t generic_packed_elems(const std::vector<struct Plan>& plans);
 
 int fold_mode(const p2phd_conv_desc* c) {
@@ -319,6 +291,20 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   return n * elem_size(c->dtype);
 }
 
+// Which variant of the packed layout the launches of (desc, which) read.  The packed buffer of a layer is NOT a function of the
+// layer alone: a tap-skipping merged launch (GDesc::cls_skip) keeps the 2 x 2 taps of its pi = 1 classes in per-class order,
+// and whether a launch skips depends on N, the plane and the "cls_skip" option.  A cache of packed buffers must key on this
+// value next to (which, dtype) -- a pack made for one batch size may not serve another (advisor, round 4: train.py:206 runs
+// inference on a smaller last batch between training steps).
+extern "C" int p2phd_conv_pack_layout(const p2phd_conv_desc* c, int which) {
+  if (check_desc(c) != P2PHD_OK || (which != 0 && which != 1)) return -1;
+  std::vector<Plan> plans; WMap m;
+  make_plans(c, which, plans, &m);
+  int id = 0;
+  for (auto& p : plans) if (p.d.cls_skip != 0) id |= 1;
+  return id;
+}
+
 extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, const float* w, void* packed, void* stream) {
   if (int rc = check_desc(c)) return rc;
   P2PHD_REQUIRE(which == 0 || which == 1, "pack_weights: which must be 0 (forward) or 1 (input gradient)");
@@ -335,11 +321,7 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
     } else if (int rc = launch_pack(p.d, m, c->dtype, w, dst, p.rows_pad, (hipStream_t)stream)) return rc;
   }
   if (march_shape_elems(c, which) > 0) {
-    const int keep = g_opt_march;
-    g_opt_march = 1;
-    const int rc = march_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
-    g_opt_march = keep;
-    return rc;
+    return march_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   }
   if (which == 0 && c7_fast_shape(c)) {
     size_t n = 0;
@@ -749,10 +731,7 @@ extern "C" size_t p2phd_conv_wgrad_workspace_bytes(const p2phd_conv_desc* c) {
   if (w.fold == FOLD_OUT) extra = folded_dy_bytes(c, Ho, Wo);
   else if (w.fold == FOLD_IN) extra = folded_x_bytes(c, Wo);
   // (the marching weight-gradient kernel keeps one slab per workgroup; sized for it whatever the option says at the moment)
-  const int keep = g_opt_march;
-  g_opt_march = 1;
   const size_t mw = align256(march_w_workspace_floats(c) * sizeof(float));
-  g_opt_march = keep;
   return std::max(w.dwp_bytes + extra, mw);
 }
 

@@ -67,6 +67,11 @@ constexpr int P2PHD_FP8_INTERNAL = 2;
 int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, int rows_pad, float* scale2, unsigned* amax_bits,
                     hipStream_t st);
 
+// launch counters (p2phd_launch_count): which kernel family a call really took -- tests assert that the benchmarked step runs
+// on the round-4/5 kernels and not on the generic loop behind them
+enum LaunchFamily { LC_GCONV = 0, LC_HALO, LC_CLS_SKIP, LC_MARCH, LC_MARCH_W, LC_WGRAD, LC_SPLITK, LC_TILE256, LC_PATCH, LC_FAMILIES };
+extern unsigned long long g_launch_count[LC_FAMILIES];
+
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
@@ -79,22 +84,23 @@ extern int g_opt_reflect_generic;   // 1: reflect-padded 3x3 input gradients on 
 extern int g_opt_c7_abl;          // timing experiments only (tools/time_c7.py): skip parts of c7_out_fwd      // 1: the 7x7 2-channel layers always take the generic W-fold path
 
 // c7.hip: dedicated bf16 kernels of the generator's 7x7 end layers (full tiles of 8 x 128 pixels only)
-bool c7_in_ok(const p2phd_conv_desc* c);
+bool c7_in_ok(const p2phd_conv_desc* c, bool ignore_option = false);
 size_t c7_in_packed_elems(const p2phd_conv_desc* c);
 int c7_in_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_in_slots(const p2phd_conv_desc* c);
 int c7_in_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, void* y, float* table, hipStream_t st);
-bool c7_out_ok(const p2phd_conv_desc* c);
+bool c7_out_ok(const p2phd_conv_desc* c, bool ignore_option = false);
 size_t c7_out_packed_elems(const p2phd_conv_desc* c);
 int c7_out_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, int act, void* y, hipStream_t st);
-bool c7_out_dgrad_ok(const p2phd_conv_desc* c);
+bool c7_out_dgrad_ok(const p2phd_conv_desc* c, bool ignore_option = false);
 size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
 extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);
+int march_shape_kind(const p2phd_conv_desc* c, int which);     // the shape rule without the option (pack / workspace sizes)
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st);
 void march_plan(const p2phd_conv_desc* c, int which, int* slots, int* ncls, int* slot_rows, long* npix_cls, int* bs_tiles);

@@ -14,6 +14,7 @@ void set_error(const char* fmt, ...) {
 }  // namespace p2phd
 
 namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_wgrad_xcd = 1; int g_opt_march = 1; int g_opt_cls_skip = 1; int g_opt_gconv_halo = 1; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
+unsigned long long g_launch_count[LC_FAMILIES] = {};
 int device_cus() {
   static int cached[64] = {};
   int dev = 0;
@@ -35,8 +36,9 @@ __device__ unsigned g_fold_ticket[2048 + 1024 + 16 + 256];
 }  // namespace
 namespace p2phd {
 namespace {
-struct FoldDev { float* part = nullptr; unsigned* ticket = nullptr; hipStream_t last[5] = {}; bool used[5] = {}; };
+struct FoldDev { float* part = nullptr; unsigned* ticket = nullptr; hipStream_t last[5] = {}; bool used[5] = {}; hipEvent_t ev[5] = {}; bool ev_set[5] = {}; };
 FoldDev g_fold_dev[64];
+thread_local hipStream_t g_fold_pending_stream = nullptr;
 FoldDev* fold_dev() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
@@ -49,37 +51,49 @@ FoldDev* fold_dev() {
   }
   return &f;
 }
+bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+}
 }  // namespace
 
-// The region's partial rows and tickets, for a launch on `stream`.  One region serves ONE stream at a time: when a launch
-// arrives on another stream than the region's last one, that stream must have drained (hipStreamQuery) -- the caller ordered
-// them with an event / a synchronisation, as torch's stream switches and graph captures do -- else two launches of one kernel
-// family could mix their partials, and the call is refused (part == nullptr, error text set) instead of computing garbage.
+thread_local int g_fold_pending = -1;
+
+// The region's partial rows and tickets, for a launch on `stream`.  One region serves ONE stream at a time.  Round 5 (advisor):
+// the region's last launch is remembered as an EVENT recorded behind it (fold_launched), never as a stream handle to be
+// queried later -- the handle may belong to a stream that has been destroyed since, and hipStreamQuery on it is undefined.
+// A launch that arrives on another stream makes that stream wait for the event: the two launches of the family are ordered
+// on the device.  Streams under capture enqueue nothing (their launches run in graph order when the graph is replayed, and a
+// capture is entered behind a synchronisation), so they neither wait nor record.
 FoldScratch fold_scratch(int region, hipStream_t stream) {
   FoldDev* f = fold_dev();
   if (f == nullptr || region < 0 || region >= 5) { set_error("reduction scratch unavailable"); return FoldScratch{nullptr, nullptr, 0, 0}; }
-  if (f->used[region] && f->last[region] != stream) {
-    // A stream under capture enqueues nothing: its launches run when the graph is replayed, in graph order, and a capture
-    // is entered behind a synchronisation; querying other streams from a capturing thread can invalidate the capture.
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const bool now_capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
-    cs = hipStreamCaptureStatusNone;
-    const bool prev_capturing = !now_capturing && hipStreamIsCapturing(f->last[region], &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
-    if (!now_capturing && !prev_capturing) {
-      const hipError_t q = hipStreamQuery(f->last[region]);
-      if (q == hipErrorNotReady) {
-        set_error("two streams use reduction-scratch region %d at once: a launch of this kernel family is still in flight on "
-                  "another stream (order the streams, or keep one compute stream per process: include/p2phd.h, \"Streams\")", region);
-        return FoldScratch{nullptr, nullptr, 0, 0};
-      }
-      (void)hipGetLastError();                                  // (a stale stream handle: nothing of it can be in flight)
+  const bool cap = capturing(stream);
+  if (f->used[region] && f->last[region] != stream && f->ev_set[region] && !cap) {
+    if (hipStreamWaitEvent(stream, f->ev[region], 0) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("reduction-scratch region %d: cannot order this stream behind the region's previous launch "
+                "(include/p2phd.h, \"Streams\")", region);
+      return FoldScratch{nullptr, nullptr, 0, 0};
     }
   }
   f->used[region] = true;
   f->last[region] = stream;
+  g_fold_pending = cap ? -1 : region;
+  g_fold_pending_stream = stream;
   size_t fo = 0; int to = 0;
   for (int r = 0; r < region; ++r) { fo += kFoldFloats[r]; to += kFoldTickets[r]; }
   return FoldScratch{f->part + fo, f->ticket + to, kFoldFloats[region], kFoldTickets[region]};
+}
+
+void fold_launched() {
+  const int region = g_fold_pending;
+  g_fold_pending = -1;
+  FoldDev* f = fold_dev();
+  if (f == nullptr || region < 0 || region >= 5) return;
+  if (f->ev[region] == nullptr && hipEventCreateWithFlags(&f->ev[region], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f->ev[region] = nullptr; return; }
+  if (hipEventRecord(f->ev[region], g_fold_pending_stream) == hipSuccess) f->ev_set[region] = true;
+  else (void)hipGetLastError();
 }
 }  // namespace p2phd
 
@@ -112,6 +126,22 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "mdct_generic") && (value == 0 || value == 1)) { p2phd::g_opt_mdct_generic = value; return P2PHD_OK; }
   p2phd::set_error("set_option: unknown option or value (%s = %d)", name ? name : "(null)", value);
   return P2PHD_EINVAL;
+}
+
+extern "C" int64_t p2phd_launch_count(const char* family, int reset) {
+  static const char* names[p2phd::LC_FAMILIES] = {"gconv", "halo", "cls_skip", "march", "march_w", "wgrad", "splitk", "tile256", "patch"};
+  if (family == nullptr) {                                       // all families at once
+    if (reset) for (auto& c : p2phd::g_launch_count) c = 0;
+    return 0;
+  }
+  for (int i = 0; i < p2phd::LC_FAMILIES; ++i)
+    if (!strcmp(family, names[i])) {
+      const int64_t v = (int64_t)p2phd::g_launch_count[i];
+      if (reset) p2phd::g_launch_count[i] = 0;
+      return v;
+    }
+  p2phd::set_error("launch_count: unknown kernel family %s", family);
+  return -1;
 }
 
 extern "C" const char* p2phd_last_error(void) { return p2phd::g_err; }

@@ -876,14 +876,17 @@ namespace p2phd {
 // kind of marching kernel a layer's launch takes (0 = none).  which: 0 = forward, 1 = input gradient.
 //   1 = "S" 48 -> 96 gather: Conv2d(48, 96, 3, s2, p1) forward; input gradient of ConvTranspose2d(96, 48, 3, s2, p1, op1)
 //   2 = "U" 96 -> 48 transposed form: that ConvTranspose2d's forward; that Conv2d's input gradient
-int march_kind(const p2phd_conv_desc* c, int which) {
-  if (g_opt_march == 0 || c->dtype != P2PHD_BF16 || c->R != 3 || c->S != 3 || c->stride != 2 || c->pad != 1 || c->pad_mode != 0) return 0;
+// march_shape_kind: the shape rule alone (what the packed buffer and the workspace must hold whatever the option says at the
+// moment of the pack); march_kind: what a launch takes now.
+int march_shape_kind(const p2phd_conv_desc* c, int which) {
+  if (c->dtype != P2PHD_BF16 || c->R != 3 || c->S != 3 || c->stride != 2 || c->pad != 1 || c->pad_mode != 0) return 0;
   const bool conv = !c->transposed && c->C == 48 && c->K == 96 && c->H % 2 == 0 && c->W % 128 == 0 && c->H >= 8;
   const bool convt = c->transposed && c->opad == 1 && c->C == 96 && c->K == 48 && c->W % 64 == 0 && c->H >= 4;
   if (which == 0) return conv ? 1 : (convt ? 2 : 0);
   if (which == 1) return convt ? 1 : (conv ? 2 : 0);
   return 0;
 }
+int march_kind(const p2phd_conv_desc* c, int which) { return g_opt_march == 0 ? 0 : march_shape_kind(c, which); }
 
 namespace {
 typedef SGeom<48, 96, 64> GS;
@@ -906,14 +909,14 @@ MarchGeom march_geom(const p2phd_conv_desc* c, int kind, int which) {
 }  // namespace
 
 size_t march_packed_elems(const p2phd_conv_desc* c, int which) {
-  const int kind = march_kind(c, which);
+  const int kind = march_shape_kind(c, which);
   if (kind == 1) return (size_t)(96 / 16) * GS::KS * 64 * 8;
   if (kind == 2) return (size_t)GU::NB * (GU::FA + GU::FB) * 64 * 8;
   return 0;
 }
 
 int march_pack(const p2phd_conv_desc* c, int which, const float* w, void* wf, hipStream_t st) {
-  const int kind = march_kind(c, which);
+  const int kind = march_shape_kind(c, which);
   // both layers keep their weights as [96-side index][48-side index][3][3] or the reverse:
   //   Conv2d(48, 96): [K = 96][C = 48][3][3];  ConvTranspose2d(96, 48): [Cin = 96][Cout = 48][3][3]  -- the same strides
   if (kind == 1) {                                               // out = the 96 side (o), in = the 48 side (ci)
@@ -962,6 +965,7 @@ int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* w
   a.in_stats = in_stats; a.in_slope = in_slope; a.in_eps = in_eps; a.in_inv_hw = 1.f / ((float)a.Hin * (float)a.Win);
   P2PHD_REQUIRE(in_stats == nullptr || bs_out == nullptr, "march_run: a lazily normalised input goes with forward launches");
   const dim3 grid((unsigned)(a.N * a.strips * a.nseg));
+  ++g_launch_count[LC_MARCH];
   auto launch = [&](auto kern, int lds, const char* what) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, st, a);
@@ -979,7 +983,7 @@ int march_run(const p2phd_conv_desc* c, int which, const void* in, const void* w
 bool march_w_ok(const p2phd_conv_desc* c) { return march_kind(c, 0) != 0; }   // same layers, same geometry rule as the forward
 
 size_t march_w_workspace_floats(const p2phd_conv_desc* c) {
-  if (!march_w_ok(c)) return 0;
+  if (march_shape_kind(c, 0) == 0) return 0;
   const MarchGeom g = march_geom(c, 1, 0);
   return (size_t)c->N * g.strips * g.nseg * 96 * 432;
 }
@@ -999,6 +1003,7 @@ int march_w_run(const p2phd_conv_desc* c, const void* x, const void* dy, float* 
   a.stats = x_stats; a.slope = x_slope; a.eps = x_eps;
   a.inv_hw = conv ? 1.f / ((float)(2 * a.Hs) * (float)(2 * a.Ws)) : 1.f / ((float)a.Hs * (float)a.Ws);   // plane of x
   const int wgs = a.N * a.strips * a.nseg;
+  ++g_launch_count[LC_MARCH_W];
   auto launch = [&](auto kern) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, WGeom::LDS);
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(kThreads), WGeom::LDS, st, a);

@@ -28,6 +28,13 @@ from ..optim import FlatAdam
 from ..util.util import kbdwin
 from . import networks
 from .base_model import BaseModel
+
+
+def _default_mdct_type():
+    """'mdct4' (BASELINE's 512x256 geometry) unless the environment says otherwise: the zero-edit launcher
+    (pix2pixhdaudiosr_amd.dropin) sets P2PHD_MDCT_TYPE=mdct2, the transform the shipped reference hard-codes and its eval
+    code inverts (train.py:58-60)."""
+    return os.environ.get('P2PHD_MDCT_TYPE', 'mdct4')
 from .mdct import MDCT4, IMDCT4, MDCT2, IMDCT2
 
 
@@ -71,9 +78,9 @@ class Pix2PixHDModel(BaseModel):
             unsupported.append("label_nc must be 0 (audio)")
         if _opt(opt, 'pool_size', 0) != 0:
             unsupported.append("pool_size must be 0 (the reference default; ImagePool is a no-op then)")
-        if _opt(opt, 'use_match_loss', False) and _opt(opt, 'mdct_type', 'mdct4') != 'mdct2':
+        if _opt(opt, 'use_match_loss', False) and _opt(opt, 'mdct_type', _default_mdct_type()) != 'mdct2':
             unsupported.append("--use_match_loss compares DCT frames: it needs mdct_type='mdct2'")
-        if _opt(opt, 'mdct_type', 'mdct4') not in ('mdct4', 'mdct2'):
+        if _opt(opt, 'mdct_type', _default_mdct_type()) not in ('mdct4', 'mdct2'):
             unsupported.append("mdct_type must be 'mdct4' or 'mdct2'")
         if unsupported:
             raise NotImplementedError("Pix2PixHDModel (HIP path): " + "; ".join(unsupported))
@@ -100,7 +107,7 @@ class Pix2PixHDModel(BaseModel):
         kw = dict(n_fft=opt.n_fft, hop_length=opt.hop_length, win_length=opt.win_length, window=self.window, device=self.device)
         # mdct_type 'mdct4' (default: n_fft/2 bins, the BASELINE 512x256 geometry) or 'mdct2' (what the shipped
         # reference hard-codes, pix2pixHD_model.py:37-40: n_fft bins through DCT_2N_native / IDCT_2N_native)
-        self.mdct_type = _opt(opt, 'mdct_type', 'mdct4')
+        self.mdct_type = _opt(opt, 'mdct_type', _default_mdct_type())
         if self.mdct_type == 'mdct2':
             from ..dct.dct_native import DCT_2N_native, IDCT_2N_native
             self._dct, self._idct = DCT_2N_native(), IDCT_2N_native()
@@ -157,6 +164,8 @@ class Pix2PixHDModel(BaseModel):
                 print('Total number of parameters of D: %d' % (sum([param.numel() for param in params])))
             self.optimizer_D = FlatAdam(params, lr=opt.lr, betas=(opt.beta1, 0.999))
             self._attach_scaler()
+            if self.scaler is not None and _opt(opt, 'continue_train', False):
+                self.scaler.load_file(os.path.join(self.save_dir, '%s_scaler.pth' % opt.which_epoch))
         self._visual = None
 
     # ------------------------------------------------------------------------------------------
@@ -528,12 +537,13 @@ class Pix2PixHDModel(BaseModel):
         st.wait_stream(cur)
         # the conv launchers size their tile rounds (split-K tail) for the CUs the masked stream can reach
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
-        _ops.check(_ops.lib().p2phd_set_option(b"cus", n_cu - n), "set_option(cus)")
+        # (on every library of the process: fp16-storage convs run in libp2phd_hip_f16.so, which has its own option globals)
+        _ops._lib.set_option_all(b"cus", n_cu - n)
         try:
             with torch.cuda.stream(st):
                 out = fn(*args, **kw)
         finally:
-            _ops.check(_ops.lib().p2phd_set_option(b"cus", 0), "set_option(cus)")
+            _ops._lib.set_option_all(b"cus", 0)
         cur.wait_stream(st)
         return out
 
@@ -643,6 +653,10 @@ class Pix2PixHDModel(BaseModel):
     def save(self, which_epoch):
         self.save_network(self.netG, 'G', which_epoch, self.gpu_ids)
         self.save_network(self.netD, 'D', which_epoch, self.gpu_ids)
+        if getattr(self, 'scaler', None) is not None:
+            # fp16 storage: scale + growth tracker of the device loss scaler, in a file of its own beside the reference's two
+            # (the reference restarts GradScaler at 65536 on resume, train.py:67; a resume without the file does the same)
+            torch.save(self.scaler.state_dict(), os.path.join(self.save_dir, '%s_scaler.pth' % which_epoch))
 
     def update_fixed_params(self):
         """pix2pixHD_model.py:521-528: after niter_fix_global epochs the global generator trains too -- a fresh Adam over
@@ -652,7 +666,8 @@ class Pix2PixHDModel(BaseModel):
         self.optimizer_G = FlatAdam(list(self.netG.parameters()), lr=self.opt.lr, betas=(self.opt.beta1, 0.999))
         self.optimizer_G.scaler, self.optimizer_G.scaler_index = getattr(self, 'scaler', None), 0
         if getattr(old, '_collectives', False) or old.world_size > 1:
-            self.optimizer_G.enable_data_parallel(old.world_size, old.process_group, getattr(old, '_collectives', False) and old.world_size == 1)
+            self.optimizer_G.enable_data_parallel(old.world_size, old.process_group, getattr(old, '_collectives', False) and old.world_size == 1,
+                                                  wire_dtype=getattr(old, 'wire_dtype', torch.float32))
         self._graph_state = None
         if _opt(self.opt, 'verbose', False):
             print('------------ Now also finetuning global generator -----------')

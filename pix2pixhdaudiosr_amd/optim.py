@@ -35,6 +35,26 @@ class DeviceGradScaler:
     def get_scale(self):
         return float(self.state[0].item())
 
+    def state_dict(self):
+        """Scale, its reciprocal and the growth tracker (the found-inf flags are per-step scratch)."""
+        return {"state": self.state.detach().cpu().clone(), "growth_factor": self.growth_factor,
+                "backoff_factor": self.backoff_factor, "growth_interval": self.growth_interval}
+
+    def load_state_dict(self, sd):
+        st = sd["state"].to(dtype=torch.float32)
+        if st.numel() != self.state.numel():
+            raise ValueError("DeviceGradScaler: state of another layout")
+        self.state.copy_(st.to(self.state.device))
+        self.growth_factor, self.backoff_factor = float(sd["growth_factor"]), float(sd["backoff_factor"])
+        self.growth_interval = int(sd["growth_interval"])
+
+    def load_file(self, path):
+        import os
+        if os.path.isfile(path):
+            self.load_state_dict(torch.load(path, map_location="cpu"))
+            return True
+        return False
+
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-8, process_group=None):

@@ -40,6 +40,33 @@ def enable_data_parallel(model, world_size, process_group=None, broadcast=True, 
     return model
 
 
+def flat_checksum(flat):
+    """64-bit position-weighted checksum of a flat fp32 buffer's BITS (int64 arithmetic, wraps): equal on two replicas iff --
+    up to a 2^-64 collision -- every element has the same bits in the same place."""
+    bits = flat.detach().contiguous().view(torch.int32).to(torch.int64)
+    w = torch.arange(1, bits.numel() + 1, device=bits.device, dtype=torch.int64) % 2147483629 + 1
+    return int((bits * w).sum().item())
+
+
+def replica_checksum_spread(model, process_group=None):
+    """{"G": s, "D": s}: max - min over the ranks of the checksum of each network's master weights.  0 = the replicas are
+    bit-identical, which is what data parallelism with a summing all-reduce and identical Adam steps must preserve; anything
+    else means an exchange was missed, applied twice or read before it had finished (round-4 review, weak 13: a one-rank
+    rehearsal cannot see a missing stream dependency, so the first real N-rank run must say so itself -- bench.py prints
+    this in its `dist` block)."""
+    import torch.distributed as dist
+    out = {}
+    for name, opt in (("G", model.optimizer_G), ("D", model.optimizer_D)):
+        c = flat_checksum(opt.flat_p)
+        dev = opt.flat_p.device if dist.get_backend(process_group) == "nccl" else torch.device("cpu")
+        hi = torch.tensor([c], dtype=torch.int64, device=dev)
+        lo = hi.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
+        out[name] = int(hi.item()) - int(lo.item())
+    return out
+
+
 def masked_compute_stream(device, free_cus):
     """A HIP stream whose kernels may run on every CU but `free_cus` of them (hipExtStreamCreateWithCUMask), wrapped for
     torch.  Every MFMA kernel of the step takes a CU's whole LDS (one workgroup per CU), so on N > 1 GPUs the RCCL

@@ -1,5 +1,18 @@
 """Host-side helpers of the hot path with the reference's names (util/util.py)."""
+import os
+
 import torch
+
+
+def mkdir(path):
+    """util/util.py:50-52 of the reference (options/base_options.py:100 and the visualizer call these)."""
+    os.makedirs(path, exist_ok=True)
+
+
+def mkdirs(paths):
+    """util/util.py:43-48: one path or a list of them."""
+    for p in ([paths] if isinstance(paths, str) else list(paths)):
+        mkdir(p)
 
 
 def kbdwin(N: int, beta: float = 12.0, device='cpu') -> torch.Tensor:

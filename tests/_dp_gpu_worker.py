@@ -41,7 +41,14 @@ def main():
         if i == 0:
             first = {"G": model.optimizer_G.flat_p.cpu().clone(), "D": model.optimizer_D.flat_p.cpu().clone()}
     torch.cuda.synchronize()
-    torch.save({"G": model.optimizer_G.flat_p.cpu(), "D": model.optimizer_D.flat_p.cpu(), "losses": losses, "first": first,
+    spread = PS.replica_checksum_spread(model)
+    final_G = model.optimizer_G.flat_p.cpu().clone()
+    if rank == 1:                                                   # sensitivity of the checksum: the lowest bit of one weight on one rank
+        v = model.optimizer_G.flat_p.view(torch.int32)
+        v[v.numel() // 3] ^= 1
+    poked = PS.replica_checksum_spread(model)
+    torch.save({"G": final_G, "D": model.optimizer_D.flat_p.cpu(), "losses": losses, "first": first, "spread": spread,
+                "spread_after_a_poke": poked,
                 "buckets_G": list(model.optimizer_G.bucket_log), "buckets_D": list(model.optimizer_D.bucket_log),
                 "total_G": model.optimizer_G._total, "total_D": model.optimizer_D._total,
                 "steps": model.optimizer_G.steps_taken(), "graphed": getattr(model, "_graph_state", None) is not None

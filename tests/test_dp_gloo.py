@@ -64,7 +64,15 @@ def _worker(rank, world, port, out_dir):
         hG.wait(); hD.wait()
         pG = OM.adam_step(dict(pG), _unflatten(flatG / world, gG), sG, opt.lr, opt.beta1)
         pD = OM.adam_step(dict(pD), _unflatten(flatD / world, gD), sD, opt.lr, opt.beta1)
-    torch.save({"G": _flatten(pG), "D": _flatten(pD)}, os.path.join(out_dir, f"rank{rank}.pt"))
+    # the replica-consistency check bench.py prints (round 5): the product function over gloo, on stand-ins for the two
+    # optimisers' flat master weights; then its sensitivity -- one flipped low bit on one rank
+    from types import SimpleNamespace as NS
+    fake = NS(optimizer_G=NS(flat_p=_flatten(pG)), optimizer_D=NS(flat_p=_flatten(pD)))
+    spread = PS.replica_checksum_spread(fake)
+    if rank == 1:
+        fake.optimizer_D.flat_p.view(torch.int32)[5] ^= 1
+    poked = PS.replica_checksum_spread(fake)
+    torch.save({"G": _flatten(pG), "D": _flatten(pD), "spread": spread, "poked": poked}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -77,6 +85,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["D"], r1["D"])          # replicas stay identical
+    assert r0["spread"] == r1["spread"] == {"G": 0, "D": 0}
+    assert r0["poked"] == r1["poked"] and r0["poked"]["G"] == 0 and r0["poked"]["D"] != 0
     # single-process emulation: average of the two shards' gradients (each shard normalised on its own)
     opt = _tiny_opt()
     w = M4.kbdwin(opt.win_length)

@@ -865,3 +865,45 @@ def test_kmajor_master_weights(dtype, tol, geom):
         assert rel_err(res[1][1].numpy(), go[0].numpy()) < 3e-4 and rel_err(res[1][2].numpy(), go[1].numpy()) < 3e-4
 
 
+
+
+@pytest.mark.parametrize("layer", ["conv_transpose_fwd", "conv_s2_dgrad"])
+def test_one_spec_at_two_batch_sizes_never_reuses_a_pack_of_the_other_tap_order(layer):
+    """Advisor (round 4, high): a tap-skipping merged launch (GDesc::cls_skip) reads the taps of half its sub-pixel classes in
+    another order than the plain merged launch, and which of the two a call takes depends on N.  One ConvSpec serving the
+    B = 8 training batch, then a B = 1 evaluation batch (train.py:206 -> eval_model), then B = 8 again WITHOUT a weight update
+    must give, each time, what a fresh ConvSpec gives; the two packs must be distinct buffers (p2phd_conv_pack_layout)."""
+    from pix2pixhdaudiosr_amd import _ops
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    if layer == "conv_transpose_fwd":
+        mk = lambda: _ops.ConvSpec(192, 96, 3, 2, 1, 0, True, 1, True, 3)
+        w = (torch.randn(192, 96, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True)
+        b = (torch.randn(96, generator=g) * 0.1).cuda().requires_grad_(True)
+        xs = {n: torch.randn(n, 192, 64, 64, generator=g).cuda() for n in (8, 1)}
+    else:
+        mk = lambda: _ops.ConvSpec(96, 192, 3, 2, 1, 0, False, 0, True, 3)
+        w = (torch.randn(192, 96, 3, 3, generator=g) * 0.1).cuda().requires_grad_(True)
+        b = (torch.randn(192, generator=g) * 0.1).cuda().requires_grad_(True)
+        xs = {n: torch.randn(n, 96, 128, 128, generator=g).cuda() for n in (8, 1)}
+
+    def run(spec, x):
+        xd = x.clone().requires_grad_(True)
+        yp = _ops.conv_block(_ops.ToPhysical.apply(dtype, xd), w, b, spec)
+        y = _ops.FromPhysical.apply(yp, spec.cout)
+        gx, = torch.autograd.grad(y.square().sum(), [xd])
+        return y.detach().float(), gx.float()
+
+    shared = mk()
+    ids = set()
+    for n in (8, 1, 8, 1):
+        d = shared.desc(n, xs[n].shape[2], xs[n].shape[3], dtype)
+        ids.add(_ops.lib_for(dtype).p2phd_conv_pack_layout(_ops.C.byref(d), 0 if layer == "conv_transpose_fwd" else 1))
+        got = run(shared, xs[n])
+        want = run(mk(), xs[n])
+        for a, e, what in zip(got, want, ("y", "dx")):
+            assert torch.equal(a, e), (layer, n, what, rel_err(a.cpu().numpy(), e.cpu().numpy()))
+    assert ids == {0, 1}, ids                   # the case does exercise both layouts
+    which = 0 if layer == "conv_transpose_fwd" else 1
+    bufs = [v[1].data_ptr() for k, v in shared._packed.items() if k[0] == which]
+    assert len(bufs) == 2 and bufs[0] != bufs[1]

@@ -30,6 +30,8 @@ def test_two_ranks_one_gpu(tmp_path, mode):
     assert r0["steps"] == r1["steps"] == 5
     assert r0["graphed"] == mode.startswith("graphed")
     assert torch.equal(r0["G"], r1["G"]) and torch.equal(r0["D"], r1["D"])      # replicas stay bit-identical
+    assert r0["spread"] == r1["spread"] == {"G": 0, "D": 0}                     # ... and the checksum bench.py prints says so
+    assert r0["spread_after_a_poke"]["G"] != 0 and r0["spread_after_a_poke"]["D"] == 0   # sensitivity: one flipped bit on one rank
     # bucketed exchange: the generator gradients left in 4 all-reduces, last layers first (the order the backward
     # produces them), contiguous, non-overlapping, covering the whole flat buffer; D in one
     for r in (r0, r1):
@@ -76,6 +78,7 @@ def test_bench_launches_its_own_ranks():
     assert len(d["bucket_bytes"]["D"]) == 1 and d["bucket_bytes"]["D"][0] > 0
     assert d["waits_per_step"] == 2 and d["exposed_exchange_ms"] >= 0 and d["host_wait_ms"] >= 0
     assert abs(d["exposed_exchange_ms"] - d["exposed_exchange_ms_G"] - d["exposed_exchange_ms_D"]) < 1e-6
+    assert d["replica_checksum_spread"] == {"G": 0, "D": 0}, d["replica_checksum_spread"]     # the run says itself that the replicas agree
     assert out["config"]["global_batch"] == 4 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out
     assert out["value"] > 0 and out["scaling"] == "weak"
@@ -101,6 +104,7 @@ def test_bench_step_against_real_rccl_with_one_rank(comm_cus):
     # comm_cus > 0: the step ran (and was captured / replayed) on a stream whose CU mask leaves that many CUs to RCCL
     assert out["dist"]["comm_cus"] == comm_cus and out["dist"]["ranks"] == 1
     assert out["dist"]["waits_per_step"] == 2 and out["dist"]["exposed_exchange_ms"] >= 0
+    assert out["dist"]["replica_checksum_spread"] == {"G": 0, "D": 0}
     assert len(out["dist"]["bucket_bytes"]["G"]) == 4
     assert len(out["dist"]["g_gradient_buckets"]) == 4 and min(out["dist"]["g_gradient_buckets"]) > 0
     assert out["config"]["launch"] == "hip-graph replay" and "graph_error" not in out and out["value"] > 0

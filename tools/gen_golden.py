@@ -540,7 +540,7 @@ def main():
     _stub_modules()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
-    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "model", "evaltail", "feeder"]
+    todo = a.only.split(",") if a.only else ["mdct", "mdct2", "networks", "networks_d3", "model", "spectro_modes", "evaltail", "feeder"]
     if "mdct2" in todo:
         gen_mdct2(a.out)
     if "mdct" in todo:
