@@ -253,22 +253,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   const auto rsB = __builtin_amdgcn_make_buffer_rsrc((void*)wp, 0, (int)d.w_bytes, 0x00020000);
 
   // byte offsets of this thread's four A pieces for the next K slab
-  // K order of the slabs (GDesc::k_chunk_major, round 5).  0: (tap, channel) -- slab s = 128 bytes at K offset 128 s of the
-  // packed row.  1: (64-channel chunk, tap, channel) -- slab s = chunk s / T, tap s % T: the T taps of a chunk re-read the SAME
-  // 128-byte channel run of the tile's pixels one after the other, so the gathered lines are re-used out of the XCD's L2
-  // within a slab's time instead of after a whole sweep of the channels (the 256 -> 512 4 x 4 layer read 16 x its input per
-  // launch from beyond L2: 32 tiles x 227 KB of patch per XCD do not fit 4 MiB, 32 x 57 KB of one chunk do).  The packed
-  // weights keep their layout: slab (c, t) of a row is the 128 bytes at K offset t * Cp + 64 c (as in the HALO loop).
-  const bool kmaj = d.k_chunk_major != 0;
-  int b_soff = s_begin * kRowBytes;                            // byte offset inside a packed weight row of the slab `prepare` is at
-  if (kmaj) {
-    const int c0 = s_begin / T_taps;
-    a_t = s_begin - c0 * T_taps;
-    a_cB = c0 * kRowBytes + kchunk * EPP * SZ;
-    b_soff = a_t * CpB + c0 * kRowBytes;
-  }
-  // returns the weight-slab byte offset of the tile it prepared (the scalar offset of its B pieces)
-  auto prepare = [&]() -> int {
+  auto prepare = [&]() {
     if (a_t != cur_t) {
       cur_t = a_t;
       if (a_t < T_taps) {
@@ -288,18 +273,11 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     }
 #pragma unroll
     for (int i = 0; i < NA; ++i) va[i] = aoffb[i] == kOOB ? kOOB : aoffb[i] + (unsigned)a_cB;
-    const int soff = b_soff;
-    if (kmaj) {
-      ++a_t; b_soff += CpB;
-      if (a_t == T_taps) { a_t = 0; a_cB += kRowBytes; b_soff += kRowBytes - T_taps * CpB; }
-    } else {
-      a_cB += kRowBytes; b_soff += kRowBytes;
-      while (a_cB >= CpB) { a_cB -= CpB; ++a_t; }
-    }
-    return soff;
+    a_cB += kRowBytes;
+    while (a_cB >= CpB) { a_cB -= CpB; ++a_t; }
   };
   // piece j of a tile: 0..NA-1 = A rows rbase + RS j, NA.. = B rows; tile = K-slab index (scalar offset of B)
-  auto issue_piece = [&](int slot, int soff, int j) {
+  auto issue_piece = [&](int slot, int tile, int j) {
     char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
 #ifdef P2PHD_ABL_ADMA1
     if (j >= 1 && j < NA) return;                              // experiment: one A piece per thread and slab (what an LDS halo would issue)
@@ -309,7 +287,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     } else {
       char* B = A + BM * kRowBytes;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_ptr)(B + RS * (j - NA) * kRowBytes), 16, (int)boffb[j - NA],
-                                               soff, 0, 0);
+                                               tile * kRowBytes, 0, 0);
     }
   };
 
@@ -421,9 +399,9 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #pragma unroll
   for (int t = 0; t < NSTAGE; ++t) {
     if (t < nsteps) {
-      const int soff = prepare();
+      prepare();
 #pragma unroll
-      for (int j = 0; j < NLOADS; ++j) issue_piece(t, soff, j);
+      for (int j = 0; j < NLOADS; ++j) issue_piece(t, s_begin + t, j);
     }
   }
 #ifdef P2PHD_PROBE_FINE
@@ -489,10 +467,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         pend = false;
       }
       if (ks == 3 && issue_new) {
-        const int soff = prepare();
+        prepare();
 #pragma unroll
-        for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, soff, j);
-        pend = true; pend_slot = cur; pend_tile = soff;
+        for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, s_begin + s + NSTAGE, j);
+        pend = true; pend_slot = cur; pend_tile = s_begin + s + NSTAGE;
       }
 #endif
       __builtin_amdgcn_sched_barrier(0);
@@ -1950,10 +1928,6 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   // narrower tiles only for layers that would leave most of it empty
   if (d.n_extent == 0) d.n_extent = d.Cp_out;
   const int k = d.n_extent;
-  // chunk-major K order (gconv_kernel, `kmaj`): 16-bit operands, several taps, whole 64-channel chunks, no K padding tail, not a
-  // merged sub-pixel launch (whose classes use different tap subsets)
-  d.k_chunk_major = (sizeof(T) == 2 && p2phd::g_opt_k_chunk_major != 0 && d.cls_cp == 0 && d.nth * d.ntw > 1 && d.Cp_in % 64 == 0 &&
-                     d.KK == d.nth * d.ntw * d.Cp_in) ? 1 : 0;
   if constexpr (sizeof(T) == 2) {
     if (d.cls_skip != 0) {                                     // (planned for this tile: merged_plan)
       d.flat_m = 0;
