@@ -74,6 +74,14 @@ int p2phd_probe_read(float* ms_out, int cap);
  * Returns the count before the reset, -1 for an unknown name.  Counts launches recorded under graph capture once (at capture).
  * Test hook: proves which kernels a whole training step really runs on (train.py:148-184 at the benchmarked batch). */
 int64_t p2phd_launch_count(const char* family, int reset);
+/* Checker of the hand-counted LDS-DMA waits (round 5; libp2phd_hip_chk.so = the same sources with -DP2PHD_CHECK_WAITS): every
+ * wave of the gather-GEMM loops (generic and HALO) and of the weight-gradient loops logs the LDS buffer each piece it issues
+ * fills and, at every relaxed `s_waitcnt vmcnt(n)` in front of a slab barrier, checks that none of its n youngest pieces targets
+ * a buffer that is read behind that barrier.  out4[0] = violating kernel families (bit 0 generic loop, 1 HALO, 2 weight gradient,
+ * 3 its f32 form), [1] = waits checked, [2] = first offender, [3] = pieces logged.  Synchronises the device.  The product
+ * build returns P2PHD_EUNSUPPORTED.  p2phd_set_option("cw_inject", 1) (check build only) runs the HALO loop with the too-lax
+ * wait that shipped for 1.5 h in round 4: the checker must flag it (tests/test_gpu_waits.py). */
+int p2phd_wait_check(unsigned* out4, int reset);
 
 /* ------------------------------------------------------------------------------------------
  * MDCT4 / IMDCT4 (models/mdct.py:461-566).  n_fft a power of two in [16, 4096].

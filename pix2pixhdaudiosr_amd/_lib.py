@@ -30,6 +30,7 @@ SIGNATURES = {
     "p2phd_probe_gconv_ex": (_i32, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "p2phd_probe_read": (_i32, [_vp, _i32]),
     "p2phd_launch_count": (_i64, [C.c_char_p, _i32]),
+    "p2phd_wait_check": (_i32, [_vp, _i32]),
     "p2phd_mdct4_tables_floats": (C.c_size_t, [_i32]),
     "p2phd_mdct4_tables_fill": (_i32, [_i32, _vp]),
     "p2phd_mdct4_frame_layout": (_i32, [_i64, _i64, _i32, _i32, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),

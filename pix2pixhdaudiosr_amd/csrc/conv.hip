@@ -78,6 +78,42 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 constexpr int kRowBytes = 128;   // bytes of K per LDS tile row
 
 // ------------------------------------------------------------------------------------------------------
+// -DP2PHD_CHECK_WAITS (libp2phd_hip_chk.so, tests/test_gpu_waits.py): a checker for the hand-counted waits of the LDS-DMA
+// pipelines.  `s_waitcnt vmcnt(n)` lets the wave's n YOUNGEST vector-memory operations stay in flight; a relaxed wait in
+// front of a slab barrier is correct only if none of those n targets a buffer that ANY wave reads behind the barrier.  That is a
+// statement about the issue order of every wave, and one wave that issued fewer pieces than its neighbours (round 4: the last
+// halo rows belong to waves 0 and 1 only) breaks it without any test noticing on most runs.  In this build every wave logs the
+// buffer id of each piece it issues (a 64-bit shift register of 4-bit tags, wave-uniform: scalar registers) and, at every
+// relaxed wait, looks at the n youngest tags: a tag inside the `forbid` set raises a device flag (p2phd_wait_check).
+// The product build compiles all of it away.
+// ------------------------------------------------------------------------------------------------------
+#ifdef P2PHD_CHECK_WAITS
+__device__ unsigned g_cw_flag[4];     // [0] violations (bit mask of kernel families), [1] relaxed waits checked, [2] first offending (family << 16 | n << 8 | tag), [3] pieces logged
+#define P2PHD_CW_DECL unsigned long long cw_log = ~0ull; unsigned cw_pieces = 0
+#define P2PHD_CW_ISSUE(tag) do { cw_log = (cw_log << 4) | (unsigned long long)((tag) & 15); ++cw_pieces; } while (0)
+#define P2PHD_CW_WAIT(family, n, forbid)                                                                            \
+  do {                                                                                                              \
+    if ((lane) == 0) {                                                                                              \
+      atomicAdd(&g_cw_flag[1], 1u);                                                                                 \
+      for (int cw_k = 0; cw_k < (n) && cw_k < 16; ++cw_k) {                                                         \
+        const unsigned cw_t = (unsigned)(cw_log >> (4 * cw_k)) & 15u;                                               \
+        if (cw_t != 15u && (((forbid) >> cw_t) & 1u)) {                                                             \
+          atomicOr(&g_cw_flag[0], 1u << (family));                                                                  \
+          atomicCAS(&g_cw_flag[2], 0u, ((unsigned)(family) << 16) | ((unsigned)(n) << 8) | cw_t);                   \
+        }                                                                                                           \
+      }                                                                                                             \
+    }                                                                                                               \
+  } while (0)
+#define P2PHD_CW_DONE() do { if ((lane) == 0 && cw_pieces) atomicAdd(&g_cw_flag[3], cw_pieces); } while (0)
+#else
+#define P2PHD_CW_DECL
+#define P2PHD_CW_ISSUE(tag) do { } while (0)
+#define P2PHD_CW_WAIT(family, n, forbid) do { } while (0)
+#define P2PHD_CW_DONE() do { } while (0)
+#endif
+enum { CW_GCONV = 0, CW_HALO = 1, CW_WGRAD = 2, CW_WGRAD_F32 = 3 };
+
+// ------------------------------------------------------------------------------------------------------
 // gather convolution
 // ------------------------------------------------------------------------------------------------------
 #ifdef P2PHD_PROBE
@@ -277,11 +313,13 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
     while (a_cB >= CpB) { a_cB -= CpB; ++a_t; }
   };
   // piece j of a tile: 0..NA-1 = A rows rbase + RS j, NA.. = B rows; tile = K-slab index (scalar offset of B)
+  P2PHD_CW_DECL;
   auto issue_piece = [&](int slot, int tile, int j) {
     char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
 #ifdef P2PHD_ABL_ADMA1
     if (j >= 1 && j < NA) return;                              // experiment: one A piece per thread and slab (what an LDS halo would issue)
 #endif
+    P2PHD_CW_ISSUE(slot);                                      // (check build: tag = the ring slot the piece fills)
     if (j < NA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(A + RS * j * kRowBytes), 16, (int)va[j], 0, 0, 0);
     } else {
@@ -407,8 +445,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_PROBE_FINE
   pf_b = __builtin_readcyclecounter();
 #endif
-  if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nsteps >= NSTAGE) {
+    P2PHD_CW_WAIT(CW_GCONV, (NSTAGE - 1) * NLOADS, 1u << 0);   // slot 0 is read behind the barrier
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
+  } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
   read_frags(0u, 0, 0);
@@ -441,8 +481,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_PROBE
         const unsigned long long pt1 = __builtin_readcyclecounter();
 #endif
-        if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) {
+          P2PHD_CW_WAIT(CW_GCONV, (NSTAGE - 2) * NLOADS, 1u << nslot);   // the next slab's slot is read behind the barrier
+          asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef P2PHD_PROBE
         const unsigned long long pt2 = __builtin_readcyclecounter();
         pr_wait += pt2 - pt1;
@@ -494,6 +536,7 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
 #ifdef P2PHD_PROBE
   pr_t1_ = pr_t1; pr_wait_ = pr_wait; pr_bar_ = pr_bar; pr_comp_ = pr_comp; nsteps_ = nsteps;
 #endif
+  P2PHD_CW_DONE();
   }  // !HALO
 #ifdef P2PHD_PROBE
   const unsigned long long pr_t2 = __builtin_readcyclecounter();
@@ -1019,6 +1062,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     pn += adv_n + ch;
   };
   // piece j of a tile: 0..3 gather panels, 4.. rows-operand panels
+  P2PHD_CW_DECL;
   auto issue_piece = [&](int slot_, int j) {
     char* A = smem + slot_ * STAGE;
 #ifdef P2PHD_ABL_WGRAD_GDMA1
@@ -1027,6 +1071,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 #ifdef P2PHD_ABL_WGRAD_ADMA1
     if (j >= PPT + 1) return;                                    // experiment: one rows-operand piece per thread and step
 #endif
+    P2PHD_CW_ISSUE(slot_);
     if (j < PPT) {
       char* G = A + TILEA + (grp * PPT + j) * PANEL + wrow8 * 128;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_ptr)G, 16, (int)vG[j], 0, 0, 0);
@@ -1142,8 +1187,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
         for (int j = 0; j < NLOADS; ++j) issue_piece(t, j);
       }
     }
-    if (nsteps >= NSTAGE) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nsteps >= NSTAGE) {
+      P2PHD_CW_WAIT(CW_WGRAD, (NSTAGE - 1) * NLOADS, 1u << 0);
+      asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 1) * NLOADS) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     read_frags(sbase, 0, 0);
@@ -1163,8 +1210,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 #ifdef P2PHD_PROBE
           const unsigned long long q0 = __builtin_readcyclecounter();
 #endif
-          if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (NSTAGE > 2 && s + NSTAGE - 1 < nsteps) {
+            P2PHD_CW_WAIT(CW_WGRAD, (NSTAGE - 2) * NLOADS, 1u << nslot);
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NSTAGE - 2) * NLOADS) : "memory");
+          } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef P2PHD_PROBE
           const unsigned long long q1 = __builtin_readcyclecounter();
 #endif
@@ -1253,8 +1302,10 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     }
     int cur = 0, nxt = D;
     for (int s = 0; s < nsteps; ++s) {
-      if (D >= 2 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLOADS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (D >= 2 && s + 1 < nsteps) {
+        P2PHD_CW_WAIT(CW_WGRAD_F32, NLOADS, 1u << cur);          // this step's slot is read behind the barrier
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLOADS) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       compute(cur, s + D < nsteps, nxt);
@@ -1263,6 +1314,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     }
   }
 
+  P2PHD_CW_DONE();
   float* slab = dwp + (size_t)bz * slab_elems;
   const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -1893,6 +1945,9 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
       }
     }
   }
+#ifdef P2PHD_CHECK_WAITS
+  d.cw_inject = p2phd::g_opt_cw_inject;
+#endif
   dim3 grid((unsigned)wgs);
   const bool probe = g_probe_cfg.on && d.Cp_in == g_probe_cfg.cp && d.KK == g_probe_cfg.kk && d.Hg == g_probe_cfg.hg &&
                      d.Wg == g_probe_cfg.wg && (g_probe_cfg.pad_mode < 0 || d.pad_mode == g_probe_cfg.pad_mode) &&
@@ -2302,6 +2357,30 @@ int launch_colsum(int dtype, const void* x, long P, int Cp, int K, float* db, in
 }
 
 }  // namespace p2phd
+
+// Wait checker (-DP2PHD_CHECK_WAITS build, libp2phd_hip_chk.so): out[0] = bit mask of the kernel families (1 gather-GEMM generic
+// loop, 2 HALO loop, 4 weight gradient, 8 its f32 form) in which a relaxed s_waitcnt vmcnt(n) left a piece in flight that
+// targets a buffer read behind the following barrier, out[1] = relaxed waits checked, out[2] = first offender
+// (family << 16 | n << 8 | buffer tag), out[3] = LDS-DMA pieces logged.  Synchronises the device.  Returns P2PHD_EUNSUPPORTED in
+// the product build (which carries no instrumentation).
+extern "C" int p2phd_wait_check(unsigned* out4, int reset) {
+#ifdef P2PHD_CHECK_WAITS
+  P2PHD_REQUIRE(out4 != nullptr, "wait_check: null pointer");
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_cw_flag), sizeof(unsigned) * 4) != hipSuccess) {
+    p2phd::set_error("wait_check: cannot read the device flag");
+    return P2PHD_ELAUNCH;
+  }
+  if (reset) {
+    const unsigned z[4] = {0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_cw_flag), z, sizeof(z)) != hipSuccess) { p2phd::set_error("wait_check: reset failed"); return P2PHD_ELAUNCH; }
+  }
+  return P2PHD_OK;
+#else
+  (void)out4; (void)reset;
+  p2phd::set_error("wait_check: this library was built without -DP2PHD_CHECK_WAITS (load libp2phd_hip_chk.so)");
+  return P2PHD_EUNSUPPORTED;
+#endif
+}
 
 extern "C" int p2phd_probe_gconv_ex(int enable, int cin_pitch, int kk, int hg, int wg, int pad_mode, int elem_bytes) {
   for (auto& e : g_probe_cfg.ev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }

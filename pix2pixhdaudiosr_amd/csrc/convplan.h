@@ -16,6 +16,7 @@ struct GDesc {
   int nth, ntw, dh0, dh_step, dw0, dw_step;   // tap (a,b): offset (dh0+a*dh_step, dw0+b*dw_step)
   int wr0, wr_step, ws0, ws_step;             // tap (a,b): kernel coordinate (wr0+a*wr_step, ws0+b*ws_step)
   int flat_m;                                 // M tiles run over all N*Hg*Wg pixels (set by the launcher)
+  int cw_inject;                              // check build only (-DP2PHD_CHECK_WAITS): 1 = run the HALO loop with round 4's too-lax slab wait (the checker's sensitivity test)
   int cls_cp;                                 // > 0: merged sub-pixel launch, GEMM column = class * cls_cp + channel,
                                               //      class (pi,pj) = (col / cls_cp) writes output pixel (2*ho+pi, 2*wo+pj)
   int n_extent;                               // GEMM N extent (= Cp_out, or 4 * cls_cp when merged)
@@ -98,7 +99,7 @@ size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
-extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
+extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo; extern int g_opt_cw_inject;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);
 int march_shape_kind(const p2phd_conv_desc* c, int which);     // the shape rule without the option (pack / workspace sizes)
 size_t march_packed_elems(const p2phd_conv_desc* c, int which);

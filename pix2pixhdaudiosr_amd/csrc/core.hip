@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace p2phd
 
-namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_wgrad_xcd = 1; int g_opt_march = 1; int g_opt_cls_skip = 1; int g_opt_gconv_halo = 1; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
+namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_wgrad_xcd = 1; int g_opt_march = 1; int g_opt_cls_skip = 1; int g_opt_gconv_halo = 1; int g_opt_cw_inject = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
 unsigned long long g_launch_count[LC_FAMILIES] = {};
 int device_cus() {
   static int cached[64] = {};
@@ -116,6 +116,9 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "march") && (value == 0 || value == 1)) { p2phd::g_opt_march = value; return P2PHD_OK; }
   if (name && !strcmp(name, "cls_skip") && (value == 0 || value == 1)) { p2phd::g_opt_cls_skip = value; return P2PHD_OK; }   // (changes the packed layout: repack after a change)
   if (name && !strcmp(name, "gconv_halo") && (value == 0 || value == 1)) { p2phd::g_opt_gconv_halo = value; return P2PHD_OK; }
+#ifdef P2PHD_CHECK_WAITS
+  if (name && !strcmp(name, "cw_inject") && (value == 0 || value == 1)) { p2phd::g_opt_cw_inject = value; return P2PHD_OK; }   // (check build only: see p2phd_wait_check)
+#endif
   if (name && !strcmp(name, "wgrad_xcd") && (value == 0 || value == 1)) { p2phd::g_opt_wgrad_xcd = value; return P2PHD_OK; }
   if (name && !strcmp(name, "reflect_generic") && (value == 0 || value == 1)) { p2phd::g_opt_reflect_generic = value; return P2PHD_OK; }
   if (name && !strcmp(name, "mdct_iters") && value >= 0 && value <= 8) { p2phd::g_opt_mdct_iters = value; return P2PHD_OK; }

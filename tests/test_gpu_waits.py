@@ -1,0 +1,99 @@
+"""Round-4 review, weak 2 / item 2(a): nothing but reading guarded the hand-counted `s_waitcnt vmcnt(n)` of the LDS-DMA
+pipelines, and a wrong one (a wave whose youngest load was not the piece the count assumed) shipped for 1.5 h and failed one
+run in four.  `libp2phd_hip_chk.so` is the library built with -DP2PHD_CHECK_WAITS: every wave logs which LDS buffer each piece it
+issues fills and, at EVERY relaxed wait in front of a slab barrier -- the generic gather-GEMM loop on its 2- and 3-slot rings, the
+HALO loop, the weight-gradient loops (bf16 and f32) --, checks that none of the n pieces the wait leaves in flight targets a
+buffer read behind that barrier (csrc/conv.hip, P2PHD_CW_*).  ONE pass over the layer shapes, no repetition: the check is on the
+issue order, which is deterministic, not on timing.  Sensitivity: the same build run with round 4's too-lax HALO wait
+(p2phd_set_option("cw_inject", 1)) must raise the flag."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHK = os.path.join(ROOT, "pix2pixhdaudiosr_amd", "libp2phd_hip_chk.so")
+
+WORKER = textwrap.dedent('''
+    import ctypes as C, json, sys
+    import torch
+    sys.path.insert(0, %r)
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    L = _lib.lib()
+
+    def read(reset=1):
+        out = (C.c_uint32 * 4)()
+        _ops.check(L.p2phd_wait_check(out, reset), "wait_check")
+        return list(out)
+
+    def layer(cin, cout, k, stride, pad, pad_mode, transposed, opad, N, H, W, dtype):
+        spec = _ops.ConvSpec(cin, cout, k, stride, pad, pad_mode, transposed, opad, True, _ops.ACT_RELU)
+        g = torch.Generator().manual_seed(cin + cout + k)
+        x = torch.randn(N, cin, H, W, generator=g).cuda().requires_grad_(True)
+        wshape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        w = (torch.randn(wshape, generator=g) * 0.05).cuda().requires_grad_(True)
+        b = torch.zeros(cout).cuda().requires_grad_(True)
+        y = _ops.FromPhysical.apply(_ops.conv_block(_ops.ToPhysical.apply(dtype, x), w, b, spec), cout)
+        gx, gw = torch.autograd.grad(y.float().square().mean(), [x, w])
+        assert torch.isfinite(gx).all() and torch.isfinite(gw).all()
+
+    read()
+    bf, f32 = torch.bfloat16, torch.float32
+    names = ("gconv", "halo", "cls_skip", "wgrad", "tile256", "splitk")
+    L.p2phd_launch_count(None, 1)
+    # residual-trunk geometry (HALO loop forward + input gradient, 256-row weight gradient), >= 160 tiles
+    layer(768, 768, 3, 1, 1, 1, False, 0, 28, 32, 16, bf)
+    # 256 x 256 tiles on the 2-slot ring and a split-K tail: the discriminator's 256 -> 512 4 x 4 layer
+    layer(256, 512, 4, 1, 2, 0, False, 0, 16, 65, 33, bf)
+    # 256 x 128 tiles on the 3-slot ring (relaxed waits inside the loop): 64 -> 128 4 x 4 stride 2, and its merged input gradient
+    layer(64, 128, 4, 2, 2, 0, False, 0, 8, 129, 65, bf)
+    # 256 x 192 generic loop + tap-skipping merged launch: the up path, and a stride-2 down layer
+    layer(192, 96, 3, 2, 1, 0, True, 1, 8, 64, 64, bf)
+    layer(96, 192, 3, 2, 1, 0, False, 0, 8, 128, 128, bf)
+    # 256 x 64 tiles (3-slot ring) and the narrow 128-row tiles
+    layer(64, 64, 3, 1, 1, 1, False, 0, 8, 64, 32, bf)
+    layer(32, 32, 3, 1, 1, 0, False, 0, 2, 24, 20, bf)
+    # f32 (parity mode): generic loop + the f32 weight-gradient loop
+    layer(64, 128, 3, 1, 1, 1, False, 0, 4, 32, 32, f32)
+    layer(128, 64, 4, 2, 2, 0, False, 0, 4, 33, 17, f32)
+    counts = {k: int(L.p2phd_launch_count(k.encode(), 0)) for k in names}
+    clean = read()
+    # sensitivity: the trunk layer again under round 4's first (racy) slab wait of the HALO loop
+    _ops.check(L.p2phd_set_option(b"cw_inject", 1), "cw_inject")
+    layer(768, 768, 3, 1, 1, 1, False, 0, 28, 32, 16, bf)
+    _ops.check(L.p2phd_set_option(b"cw_inject", 0), "cw_inject")
+    injected = read()
+    print("RESULT " + json.dumps({"clean": clean, "injected": injected, "counts": counts}))
+''') % ROOT
+
+
+def test_no_relaxed_wait_leaves_a_piece_of_the_next_slab_in_flight():
+    assert os.path.isfile(CHK), "libp2phd_hip_chk.so has not been built (make -C pix2pixhdaudiosr_amd/csrc)"
+    env = dict(os.environ, P2PHD_LIB=CHK)
+    r = subprocess.run([sys.executable, "-c", WORKER], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    clean, injected, counts = res["clean"], res["injected"], res["counts"]
+    print(f"wait checker: {clean[1]} relaxed waits checked over {clean[3]} logged LDS-DMA pieces, violations mask {clean[0]:#x}; "
+          f"with the round-4 race injected: mask {injected[0]:#x}, first offender {injected[2]:#x}; launches {counts}")
+    # the pass did go through every loop with a relaxed wait
+    assert counts["halo"] >= 2 and counts["wgrad"] >= 8 and counts["tile256"] >= 1 and counts["cls_skip"] >= 2, counts
+    assert clean[1] > 1000 and clean[3] > 100000, clean
+    assert clean[0] == 0, f"a relaxed wait leaves a next-slab piece in flight: families {clean[0]:#x}, first offender {clean[2]:#x}"
+    # the checker is not blind: round 4's wait is flagged, in the HALO family (bit 1), as a weight-ring piece (tag 0 / 1) left
+    # in flight by vmcnt(1)
+    assert injected[0] & 2, injected
+    assert (injected[2] >> 16) == 1 and ((injected[2] >> 8) & 255) == 1 and (injected[2] & 255) in (0, 1), hex(injected[2])
+
+
+def test_the_product_library_carries_no_instrumentation():
+    import ctypes as C
+    from pix2pixhdaudiosr_amd import _lib
+    out = (C.c_uint32 * 4)()
+    assert _lib.lib().p2phd_wait_check(out, 0) != 0
+    assert b"P2PHD_CHECK_WAITS" in _lib.lib().p2phd_last_error()
+    assert _lib.lib().p2phd_set_option(b"cw_inject", 1) != 0
