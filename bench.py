@@ -32,6 +32,26 @@ M_D = 8.98e9                      # conv MACs / sample, MultiscaleDiscriminator 
 
 HALF = torch.bfloat16              # --fp16-storage: torch.float16 (the fp16 build of the library serves every launch)
 
+# --config: the headline workload is BASELINE configs[1] ("cfg2" in SURVEY 8d's numbering); the two others are NON-headline
+# variants (round-4 review item 5) whose JSON line says so (`headline: false`), names its configuration in config.workload and
+# prices ITS dominant kernel in `roofline`.  step_gflop: SURVEY 8(d), per sample and step, minimal result-identical schedule.
+# trunk = (channels, plane rows, plane columns) of the residual trunk's Conv3x3 behind ReflectionPad2d(1): the layer with the most
+# MACs of each generator.
+WORKLOADS = {
+    "cfg2": dict(overrides={}, frames=256, batch=32, step_gflop=None, trunk=(768, 32, 16), headline=True,
+                 workload="configs[1]: ngf=48 n_local_enhancers=0 (GlobalGenerator nd4 nb9) + MultiscaleDiscriminator "
+                          "num_D=2, 512x256 MDCT4 (n_fft 1024, hop 512), LSGAN + feature matching, Adam, bf16 MFMA"),
+    "cfg3": dict(overrides=dict(netG="local", n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2), frames=256, batch=32,
+                 step_gflop=398.0, trunk=(1536, 16, 8), headline=False,
+                 workload="configs[2]/[3] per-rank workload: GEN_VCTK_G3L2_48ngf as the reference's opt.txt reads it (LocalEnhancer ngf 48, "
+                          "4 global down-samplings, 3 global blocks, 1 local enhancer, 2 local blocks: 156 050 690 parameters) + "
+                          "MultiscaleDiscriminator num_D=2, 512x256 MDCT4, LSGAN + feature matching, Adam, bf16 MFMA"),
+    "cfg5": dict(overrides=dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048,
+                                num_D=3), frames=512, batch=8, step_gflop=3994.0, trunk=(2048, 32, 16), headline=False,
+                 workload="configs[4] per-rank workload: n_fft 2048 (1024x512 MDCT4 spectrograms), LocalEnhancer ngf 64 (730 713 346 "
+                          "parameters), 3-scale MultiscaleDiscriminator, LSGAN + feature matching, Adam, bf16 MFMA (--fp8: + e4m3 forward of the wide convs)"),
+}
+
 
 def make_opt(batch, dtype_bf16=True, fp8=False, fp16_storage=False):
     return SimpleNamespace(
@@ -46,24 +66,26 @@ def make_opt(batch, dtype_bf16=True, fp8=False, fp16_storage=False):
         lambda_feat=10.0, fp16=dtype_bf16, fp16_storage=fp16_storage, fp8=fp8, niter_decay=100, instance_feat=False, label_feat=False, batchSize=batch)
 
 
-def time_trunk_conv(batch, iters=20):
+def time_trunk_conv(batch, iters=20, trunk=(768, 32, 16)):
     """Average launch duration (HIP events on the launch stream) of the dominant kernel: Conv3x3 768->768 on
-    [B,32,16,768] bf16 behind ReflectionPad2d(1) -- 18 of the 28 generator convs, 80 % of its MACs."""
+    [B,32,16,768] bf16 behind ReflectionPad2d(1) -- 18 of the 28 generator convs, 80 % of its MACs (`trunk` = (channels, rows,
+    columns) of the same layer in another --config)."""
     from pix2pixhdaudiosr_amd import _ops
     import ctypes as C
-    spec = _ops.ConvSpec(768, 768, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
-    x = torch.randn(batch, 32, 16, 768, device="cuda").to(HALF)
-    w = (torch.randn(768, 768, 3, 3, device="cuda") * 0.02)
-    d = spec.desc(batch, 32, 16, HALF)
+    ch, th, tw = trunk
+    spec = _ops.ConvSpec(ch, ch, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    x = torch.randn(batch, th, tw, ch, device="cuda").to(HALF)
+    w = (torch.randn(ch, ch, 3, 3, device="cuda") * 0.02)
+    d = spec.desc(batch, th, tw, HALF)
     wp = spec.packed(w, 0, d)
     y = torch.empty_like(x)
-    stats = torch.zeros(batch, 768, 2, device="cuda")
+    stats = torch.zeros(batch, ch, 2, device="cuda")
     L = _ops.lib_for(HALF)
     ws = torch.empty(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 256), dtype=torch.uint8, device="cuda")
     call = lambda: _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats),
                                                _ops.ptr(ws), _ops.stream_ptr()))
     sec = time_graphed(call, iters)
-    flops = 2.0 * batch * 32 * 16 * 768 * 768 * 9
+    flops = 2.0 * batch * th * tw * ch * ch * 9
     return sec, flops
 
 
@@ -236,7 +258,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 32; 8 for --config cfg5)")
+    ap.add_argument("--config", choices=sorted(WORKLOADS), default="cfg2",
+                    help="cfg2 (default) = BASELINE configs[1], the headline workload.  cfg3 / cfg5 = the per-rank workloads of configs[2]/[3] and "
+                         "configs[4]: NON-headline variants, marked `headline: false` in the JSON line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager step on one GPU too (default: captured HIP graph)")
     ap.add_argument("--allow-eager-fallback", action="store_true",
@@ -255,6 +280,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="variant of BASELINE configs[4]: e4m3 forward of the wide stride-1 convs on top of bf16 (NOT the headline dtype)")
     a = ap.parse_args()
+    wl = WORKLOADS[a.config]
+    if a.batch is None:
+        a.batch = wl["batch"]
 
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -306,6 +334,9 @@ def main():
         if a.fp8:
             raise SystemExit("--fp8 rides on bf16; not with --fp16-storage")
     opt = make_opt(a.batch, fp8=a.fp8, fp16_storage=a.fp16_storage)
+    for k_, v_ in wl["overrides"].items():
+        setattr(opt, k_, v_)
+    frames = wl["frames"]
     opt.gpu_ids = [local]
     opt.comm_cus = a.comm_cus
     model = create_model(opt)
@@ -314,7 +345,7 @@ def main():
     if dist_on:
         parallel_state.enable_data_parallel(model, world, force_collectives=rehearse,
                                             wire_dtype=torch.bfloat16 if a.wire_bf16 else torch.float32)
-    T = (FRAMES - 1) * opt.hop_length
+    T = (frames - 1) * opt.hop_length
     g = torch.Generator(device="cuda").manual_seed(1234 + rank)
     hr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
     lr = 0.1 * torch.randn(a.batch, T, device="cuda", generator=g)
@@ -412,16 +443,15 @@ def main():
 
     if rank == 0:
         ms = dt / a.steps * 1e3
-        frames_per_s = world * a.batch * FRAMES * a.steps / dt
+        frames_per_s = world * a.batch * frames * a.steps / dt
         # minimal result-identical schedule = (3 M_G + 8 M_D) MACs = (6 M_G + 16 M_D) FLOPs per sample
-        step_flops = (6 * M_G + 16 * M_D) * a.batch
+        step_flops = ((6 * M_G + 16 * M_D) if wl["step_gflop"] is None else wl["step_gflop"] * 1e9) * a.batch
         out = {
             "metric": "MDCT spectrogram frames/sec (G+D fwd+bwd) at 512x256",
             "value": frames_per_s, "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16+fp8(e4m3 forward of the wide convs)" if a.fp8 else ("fp16" if a.fp16_storage else "bf16"), "data": "synthetic",
-            "config": {"workload": "configs[1]: ngf=48 n_local_enhancers=0 (GlobalGenerator nd4 nb9) + MultiscaleDiscriminator "
-                                   "num_D=2, 512x256 MDCT4 (n_fft 1024, hop 512), LSGAN + feature matching, Adam, bf16 MFMA",
+            "config": {"workload": wl["workload"],
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                        "launch": "hip-graph replay" if graphed else "eager",
                        "step_tflops_per_gpu": step_flops / (dt / a.steps) / 1e12,
@@ -430,6 +460,10 @@ def main():
                                            "D(fake) forward executes ~3.5 % fewer"},
             "per_rank_ms_per_step": rank_ms,
         }
+        if not wl["headline"]:
+            out["headline"] = False
+            out["config"]["variant_of"] = ("NOT the BASELINE headline workload (configs[1], the default run): `python bench.py --config %s`; "
+                                           "metric, unit and timing protocol are the headline's" % a.config)
         if a.fp16_storage:
             out["fp16_storage"] = {"library": "libp2phd_hip_f16.so (the same sources with the 16-bit type = _Float16)",
                                    "loss_scale_after_the_run": model.scaler.get_scale(),
@@ -453,7 +487,7 @@ def main():
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     rec = json.load(f)
-                if a.batch == 32:
+                if a.batch == 32 and wl["headline"]:
                     traffic = rec["hbm_bytes_per_launch"]
                     traffic_source = {"file": "profiles/" + name, "recorded": rec.get("recorded"), "how": rec.get("how")}
                 break
@@ -469,7 +503,8 @@ def main():
                 torch.distributed.barrier()
                 torch.distributed.destroy_process_group()
             return
-        sec_iso, flops = time_trunk_conv(a.batch)
+        tch, trows, tcols = wl["trunk"]
+        sec_iso, flops = time_trunk_conv(a.batch, trunk=wl["trunk"])
         sec = sec_iso
         sec_dgrad = None
         if world == 1 and not a.no_probes:                         # extra steps on one rank only would desynchronise the collectives
@@ -481,7 +516,7 @@ def main():
                 # their launch stream, inside two extra eager steps.  The forward (reflect gather, pad_mode 1) and the
                 # input gradient (reflect adjoint, pad_mode 2) run on the same grid and are told apart by the gather's
                 # padding rule; `esize` tells the e4m3 forward of --fp8 from bf16 launches
-                _ops.check(L.p2phd_probe_gconv_ex(1, 768, 9 * 768, 32, 16, pad_mode, esize))
+                _ops.check(L.p2phd_probe_gconv_ex(1, tch, 9 * tch, trows, tcols, pad_mode, esize))
                 for _ in range(2):
                     model.train_step(lr, hr)
                 torch.cuda.synchronize()
@@ -503,7 +538,8 @@ def main():
         log(f"trunk conv {sec * 1e6:.1f} us/launch")
         out["roofline"] = {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / sec / 1e12 / BF16_DENSE_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
-                           "kernel": "gconv_kernel<bf16,256,192,HALO> implicit-GEMM Conv3x3 768->768 @32x16, forward (residual trunk, 18 of 28 generator convs)",
+                           "kernel": "gconv_kernel<bf16,256,192,HALO> implicit-GEMM Conv3x3 768->768 @32x16, forward (residual trunk, 18 of 28 generator convs)"
+                                     if wl["headline"] else f"gconv_kernel<bf16> implicit-GEMM Conv3x3 {tch}->{tch} @{trows}x{tcols}, forward (residual trunk of the global generator)",
                            "launch_us": sec * 1e6, "flops_per_launch": flops,
                            "launches_timed": "forward launches only (gather pad_mode 1); the same-shaped input-gradient launches: dgrad_launch_us",
                            "dgrad_launch_us": None if sec_dgrad is None else sec_dgrad * 1e6}
@@ -515,7 +551,7 @@ def main():
                                     "traffic": None, "traffic_source": None,
                                     "peak_note": "block-scaled e4m3 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): priced against the 5 PF dense fp8 peak",
                                     "kernel": "gconv_kernel<fp8 e4m3> implicit-GEMM Conv3x3 768->768 @32x16 (forward of the residual trunk)"})
-        if world == 1 and not a.no_probes:
+        if world == 1 and not a.no_probes and wl["headline"]:
             try:
                 tg = time_generator(model, a.batch)
                 gf = 6 * M_G * a.batch
@@ -526,10 +562,10 @@ def main():
                 log(f"generator fwd+bwd alone: {tg * 1e3:.2f} ms = {gf / tg / 1e12:.0f} TFLOP/s")
             except Exception as e:                                 # a measurement extra: never lose the headline line to it
                 log(f"generator-only timing failed: {type(e).__name__}: {e}")
-        if world == 1 and not a.no_mdct:
+        if world == 1 and not a.no_mdct and wl["headline"]:
             out["mdct"] = time_mdct(a.batch)
             log("mdct alone: " + ", ".join(f"{k} {v['us']:.1f} us {v['GB_per_s']:.0f} GB/s" for k, v in out["mdct"].items()))
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and wl["headline"]:
             log("cpu baseline (oracle, batch 2: configs[1] and configs[0] networks, 1 + 3 steps each) ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), file=_JSON_OUT or sys.stdout, flush=True)

@@ -11,6 +11,9 @@ CONFIGS = {
     "cfg1 ngf32 global nd4 nb9 fp32 B2": (dict(ngf=32, fp16=False), 2),
     "cfg2 ngf48 global bf16 B32": (dict(), 32),
     "cfg3 G3L2_48ngf (opt.txt: local nd4 nbg3 nle1 nbl2) fp32 B4": (dict(netG="local", n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2, fp16=False), 4),
+    # configs[3]'s PER-RANK workload (8 x MI355X data parallel, per-GPU batch 32, bf16): what one rank of that job runs
+    "cfg3 G3L2_48ngf (opt.txt) bf16 B32 = configs[3] per rank": (dict(netG="local", n_blocks_global=3, n_local_enhancers=1, n_blocks_local=2), 32),
+    "cfg3' (BASELINE wording) bf16 B32 = configs[3] per rank": (dict(netG="local", n_downsample_global=3, n_blocks_global=9, n_local_enhancers=2, n_blocks_local=3), 32),
     "cfg3' (BASELINE wording: local nd3 nb9 nle2 nbl3) bf16 B8": (dict(netG="local", n_downsample_global=3, n_blocks_global=9, n_local_enhancers=2, n_blocks_local=3), 8),
     "cfg5 n_fft2048 ngf64 local defaults num_D3 bf16 B4": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3), 4),
     "cfg5 + fp8 (e4m3 forward of the wide stride-1 convs) B4": (dict(netG="local", ngf=64, n_local_enhancers=1, n_blocks_local=3, n_fft=2048, hop_length=1024, win_length=2048, num_D=3, fp8=True), 4),
