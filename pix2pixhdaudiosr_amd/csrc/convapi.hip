@@ -283,6 +283,7 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   make_plans(c, which, plans, &m);
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+  if (which == 0 && dfirst_ok(c, true)) n += dfirst_packed_elems(c);        // fragment-ordered copy for dfirst.hip, behind the generic pack
   if (which == 0 && c7_fast_shape(c)) n += c7_in_packed_elems(c);           // fragment-ordered copy for c7.hip, behind the W-fold pack
   if (which == 0 && c7_out_shape(c)) n += c7_out_packed_elems(c);
   if (which == 1 && c7_dgrad_shape(c))                                       // + fragment-ordered copy + f32 master copy (border fix)
@@ -323,6 +324,8 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   if (march_shape_elems(c, which) > 0) {
     return march_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   }
+  if (which == 0 && dfirst_ok(c, true))
+    return dfirst_pack(c, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   if (which == 0 && c7_fast_shape(c)) {
     size_t n = 0;
     for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
@@ -407,6 +410,11 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
     long npix_cls = 0;
     march_plan(c, 0, &slots, &ncls, &slot_rows, &npix_cls, nullptr);
     return launch_stats_merge(table, stats, c->N, slots, ncls, cpitch(c->K), c->K, npix_cls, slot_rows, st);
+  }
+  if (fold == FOLD_NONE && stats == nullptr && dfirst_ok(c)) {
+    // the discriminator's first layer (4 -> 64, 4 x 4 stride 2): pixels straight into MFMA fragments, weights in registers (dfirst.hip)
+    const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    return dfirst_fwd(c, x, wf, bias, act, y, st);
   }
   if (fold == FOLD_IN && act == P2PHD_ACT_NONE && c7_in_ok(c)) {
     // dedicated 2-channel 7x7 kernel (c7.hip): halo once through LDS, weights in registers, whole-row stores

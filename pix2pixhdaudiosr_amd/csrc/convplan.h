@@ -98,6 +98,12 @@ bool c7_out_dgrad_ok(const p2phd_conv_desc* c, bool ignore_option = false);
 size_t c7_out_dgrad_packed_elems(const p2phd_conv_desc* c);
 int c7_out_dgrad_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int c7_out_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wf, const float* w_master, void* dx, hipStream_t st);
+// dfirst.hip: forward of the discriminator's first layer (Conv2d(<= 8, 64, 4, stride 2, padding 2) + activation, no statistics), bf16
+extern int g_opt_dfirst;
+bool dfirst_ok(const p2phd_conv_desc* c, bool ignore_option = false);
+size_t dfirst_packed_elems(const p2phd_conv_desc* c);
+int dfirst_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
+int dfirst_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, int act, void* y, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
 extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo; extern int g_opt_cw_inject;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);

@@ -66,6 +66,11 @@ CASES = [
     ("halo_fwd_128to768", 128, 768, 3, 1, 1, 1, False, 0, True, 3, (28, 32, 16), False),
     ("halo_dgrad_768to128", 768, 128, 3, 1, 1, 1, False, 0, True, 3, (28, 32, 16), False),
     ("halo_both_768_rows48", 768, 768, 3, 1, 1, 1, False, 0, True, 3, (19, 48, 16), False),
+    # round 5: the discriminator's first layer (4 -> 64, 4 x 4 stride 2, LeakyReLU, no statistics): 16-bit types take csrc/dfirst.hip
+    # (pixels straight into MFMA fragments), fp32 the generic gather-GEMM; odd planes, a last block of fewer than 16 pixels
+    ("dfirst_4to64", 4, 64, 4, 2, 2, 0, False, 0, False, 1, (3, 37, 50), False),
+    ("dfirst_4to64_tiny", 4, 64, 4, 2, 2, 0, False, 0, False, 1, (1, 5, 3), False),
+    ("dfirst_2to64_noact", 2, 64, 4, 2, 2, 0, False, 0, False, 0, (2, 16, 24), False),
 ]
 
 
@@ -907,3 +912,42 @@ def test_one_spec_at_two_batch_sizes_never_reuses_a_pack_of_the_other_tap_order(
     which = 0 if layer == "conv_transpose_fwd" else 1
     bufs = [v[1].data_ptr() for k, v in shared._packed.items() if k[0] == which]
     assert len(bufs) == 2 and bufs[0] != bufs[1]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_dfirst_kernel_equals_the_generic_path(dtype):
+    """Round 5: csrc/dfirst.hip (option dfirst = 1: the discriminator's 4 -> 64 first layer with the input pixels loaded straight
+    into MFMA fragments) against the generic gather-GEMM path it replaces (option 0), at the layer's real plane of the second
+    scale (256 x 128 -> 129 x 65) and on an odd plane: same products, fp32 accumulation in another order -> equal to the 16-bit
+    rounding of the output; and against the fp32 oracle."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _ops.lib_for(dtype)
+    for (N, H, W) in ((4, 256, 128), (3, 37, 51)):
+        gen = torch.Generator().manual_seed(H)
+        spec = _ops.ConvSpec(4, 64, 4, 2, 2, 0, False, 0, False, _ops.ACT_LRELU)
+        d = spec.desc(N, H, W, dtype)
+        Ho, Wo = spec.out_size(d)
+        xc = torch.randn(N, 4, H, W, generator=gen)
+        x = _ops.ToPhysical.apply(dtype, xc.cuda())
+        w = (torch.randn(64, 4, 4, 4, generator=gen) * 0.1).cuda()
+        b = (torch.randn(64, generator=gen) * 0.1).cuda()
+        y = torch.empty(N, Ho, Wo, 64, device="cuda", dtype=dtype)
+        wp = spec.packed(w, 0, d)
+        ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 1 << 20), "cuda")
+        res = {}
+        try:
+            for opt in (0, 1):
+                _lib.check(L.p2phd_set_option(b"dfirst", opt))
+                y.fill_(7.0)
+                _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), _ops.ptr(b), _ops.ACT_LRELU, _ops.ptr(y), None, _ops.ptr(ws), _ops.stream_ptr()))
+                torch.cuda.synchronize()
+                res[opt] = y.float().cpu().numpy().copy()
+        finally:
+            _lib.check(L.p2phd_set_option(b"dfirst", 1))
+        q = lambda t: t.to(dtype).float()
+        ref = F.leaky_relu(F.conv2d(q(xc), q(w.cpu()), b.cpu(), stride=2, padding=2), 0.2).permute(0, 2, 3, 1).numpy()
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        assert rel_err(res[1], res[0]) < ulp, rel_err(res[1], res[0])
+        assert rel_err(res[1], ref) < 2 * ulp and rel_err(res[0], ref) < 2 * ulp, (rel_err(res[1], ref), rel_err(res[0], ref))
+        assert np.abs(res[1] - ref).max() <= 4 * ulp * np.abs(ref).max()
