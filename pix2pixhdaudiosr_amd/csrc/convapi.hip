@@ -283,6 +283,7 @@ extern "C" size_t p2phd_conv_packed_bytes(const p2phd_conv_desc* c, int which) {
   make_plans(c, which, plans, &m);
   size_t n = 0;
   for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
+  if (dlast_ok(c, true)) n += dlast_packed_elems(c, which);                 // fragment-ordered copy for dlast.hip, behind the W-fold pack
   if (which == 0 && dfirst_ok(c, true)) n += dfirst_packed_elems(c);        // fragment-ordered copy for dfirst.hip, behind the generic pack
   if (which == 0 && c7_fast_shape(c)) n += c7_in_packed_elems(c);           // fragment-ordered copy for c7.hip, behind the W-fold pack
   if (which == 0 && c7_out_shape(c)) n += c7_out_packed_elems(c);
@@ -324,6 +325,8 @@ extern "C" int p2phd_conv_pack_weights(const p2phd_conv_desc* c, int which, cons
   if (march_shape_elems(c, which) > 0) {
     return march_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   }
+  if (dlast_ok(c, true))
+    return dlast_pack(c, which, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   if (which == 0 && dfirst_ok(c, true))
     return dfirst_pack(c, w, static_cast<char*>(packed) + generic_packed_elems(plans) * elem_size(c->dtype), (hipStream_t)stream);
   if (which == 0 && c7_fast_shape(c)) {
@@ -362,8 +365,9 @@ extern "C" size_t p2phd_conv_fwd_workspace_bytes(const p2phd_conv_desc* c) {
   int Ho, Wo;
   out_size(c, &Ho, &Wo);
   const int fold = fold_mode(c);
-  if (fold == FOLD_OUT)                                          // Y has the shape of the folded dy; statistics: plane pass
-    return folded_dy_bytes(c, Ho, Wo) + align256(plane_stats_scratch_floats(c->N, (long)Ho * Wo, c->K) * sizeof(float));
+  if (fold == FOLD_OUT)                                          // Y has the shape of the folded dy; statistics: plane pass  (dlast.hip: per-pixel tap partials)
+    return std::max(folded_dy_bytes(c, Ho, Wo) + align256(plane_stats_scratch_floats(c->N, (long)Ho * Wo, c->K) * sizeof(float)),
+                    dlast_ok(c, true) ? align256(dlast_fwd_workspace_floats(c) * sizeof(float)) : (size_t)0);
   std::vector<Plan> plans; WMap m;
   make_plans(c, 0, plans, &m);
   const size_t table = stat_table_bytes(plans);
@@ -386,6 +390,11 @@ extern "C" int p2phd_conv_fwd(const p2phd_conv_desc* c, const void* x, const voi
   const int fold = fold_mode(c);
   P2PHD_REQUIRE((fold == FOLD_NONE && stats == nullptr) || workspace,
                 "conv_fwd: this layer needs p2phd_conv_fwd_workspace_bytes of scratch (W-fold image / statistics partials)");
+  if (fold == FOLD_OUT && stats == nullptr && act == P2PHD_ACT_NONE && dlast_ok(c)) {
+    // the discriminator's head (512 -> 1, 4 x 4): one pass over x with the 16 taps as an MFMA dimension, then a 16-term gather (dlast.hip)
+    const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    return dlast_fwd(c, x, wf, bias, y, static_cast<float*>(workspace), st);
+  }
   if (fold == FOLD_OUT && stats == nullptr && c7_out_ok(c)) {     // the generator head: marching kernel of c7.hip
     size_t n = 0;
     for (auto& p : plans) n += (size_t)p.rows_pad * p.d.KK;
@@ -572,6 +581,11 @@ extern "C" int p2phd_conv_dgrad(const p2phd_conv_desc* c, const void* dy, const 
     const void* wf = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
     return march_run(c, 1, dy, wf, nullptr, dx, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st);
   }
+  if (kfold && dlast_ok(c)) {
+    // the discriminator's head: dx in one pass, the 16 taps as the MFMA's K (dlast.hip)
+    const void* wg = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    return dlast_dgrad(c, dy, wg, addend, dx, nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, st);
+  }
   P2PHD_REQUIRE(!(reflect || kfold) || workspace, "conv_dgrad: this layer needs p2phd_conv_dgrad_workspace_bytes of scratch");
   if (reflect && !kfold && !c->transposed && c->R == 3 && c->S == 3 && c->pad == 1 && c->stride == 1 && c->H >= 4 && c->W >= 4 &&
       !g_opt_reflect_generic) {
@@ -637,6 +651,7 @@ extern "C" size_t p2phd_conv_dgrad_bsum_workspace_bytes(const p2phd_conv_desc* c
     out_size(c, &Ho, &Wo);
     n += folded_dy_bytes(c, Ho, Wo);
   }
+  if (dlast_ok(c, true)) n = std::max(n, align256(dlast_bsum_table_floats(c) * sizeof(float)));
   return n;
 }
 
@@ -659,6 +674,16 @@ extern "C" int p2phd_conv_dgrad_bsum(const p2phd_conv_desc* c, const void* dy, c
     march_plan(c, 1, nullptr, nullptr, nullptr, nullptr, &tiles);
     const long npix = (long)c->H * c->W;
     return launch_bsum_merge(part, bstats, c->N, npix, (int)(npix / tiles), cpitch(c->C), 0, cpitch(c->C), c->C, st);
+  }
+  if (dlast_ok(c)) {
+    // the discriminator's head (dlast.hip): one partial row per wave (slot) and sample
+    const void* wg = static_cast<const char*>(wp) + generic_packed_elems(plans) * elem_size(c->dtype);
+    const float slope = prev_act == P2PHD_ACT_RELU ? 0.f : (prev_act == P2PHD_ACT_LRELU ? 0.2f : 1.f);
+    float* part = static_cast<float*>(workspace);
+    if (int rc = dlast_dgrad(c, dy, wg, addend, dx, prev_y, prev_stats, part, 1.f / ((float)c->H * (float)c->W), eps, slope, st)) return rc;
+    int bpw = 0;
+    dlast_dgrad_plan(c, &bpw, nullptr);
+    return launch_bsum_merge(part, bstats, c->N, (long)c->H * c->W, bpw * 16, cpitch(c->C), 0, cpitch(c->C), c->C, st);
   }
   p.d.bs_y = prev_y;
   p.d.bs_stats = prev_stats;

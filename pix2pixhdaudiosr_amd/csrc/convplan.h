@@ -104,6 +104,17 @@ bool dfirst_ok(const p2phd_conv_desc* c, bool ignore_option = false);
 size_t dfirst_packed_elems(const p2phd_conv_desc* c);
 int dfirst_pack(const p2phd_conv_desc* c, const float* w, void* wf, hipStream_t st);
 int dfirst_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, int act, void* y, hipStream_t st);
+// dlast.hip: the discriminator's last layer (Conv2d(C, 1, 4, stride 1, padding 2), C a multiple of 128 up to 512), bf16: forward and input gradient
+extern int g_opt_dlast;
+bool dlast_ok(const p2phd_conv_desc* c, bool ignore_option = false);
+size_t dlast_packed_elems(const p2phd_conv_desc* c, int which);
+int dlast_pack(const p2phd_conv_desc* c, int which, const float* w, void* wfrag, hipStream_t st);
+size_t dlast_fwd_workspace_floats(const p2phd_conv_desc* c);
+int dlast_fwd(const p2phd_conv_desc* c, const void* x, const void* wf, const float* bias, void* y, float* part, hipStream_t st);
+void dlast_dgrad_plan(const p2phd_conv_desc* c, int* bpw, int* slots);
+size_t dlast_bsum_table_floats(const p2phd_conv_desc* c);
+int dlast_dgrad(const p2phd_conv_desc* c, const void* dy, const void* wg, const void* addend, void* dx, const void* bs_y,
+                const float* bs_stats, float* bs_out, float bs_inv_hw, float bs_eps, float bs_slope, hipStream_t st);
 // march.hip: marching kernels of the generator's outermost stride-2 3x3 layers (bf16); which: 0 = forward, 1 = input gradient
 extern int g_opt_march; extern int g_opt_cls_skip; extern int g_opt_gconv_halo; extern int g_opt_cw_inject;            // 1 (default): eligible layers take the marching kernels, 0: the generic gather-GEMM (A/B, parity tests)
 int march_kind(const p2phd_conv_desc* c, int which);

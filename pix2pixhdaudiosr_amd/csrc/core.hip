@@ -116,6 +116,7 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "march") && (value == 0 || value == 1)) { p2phd::g_opt_march = value; return P2PHD_OK; }
   if (name && !strcmp(name, "cls_skip") && (value == 0 || value == 1)) { p2phd::g_opt_cls_skip = value; return P2PHD_OK; }   // (changes the packed layout: repack after a change)
   if (name && !strcmp(name, "gconv_halo") && (value == 0 || value == 1)) { p2phd::g_opt_gconv_halo = value; return P2PHD_OK; }
+  if (name && !strcmp(name, "dlast") && (value == 0 || value == 1)) { p2phd::g_opt_dlast = value; return P2PHD_OK; }     // (A/B, parity tests: dlast.hip vs the W-fold path)
   if (name && !strcmp(name, "dfirst") && (value == 0 || value == 1)) { p2phd::g_opt_dfirst = value; return P2PHD_OK; }   // (A/B, parity tests: dfirst.hip vs the W-fold path)
 #ifdef P2PHD_CHECK_WAITS
   if (name && !strcmp(name, "cw_inject") && (value == 0 || value == 1)) { p2phd::g_opt_cw_inject = value; return P2PHD_OK; }   // (check build only: see p2phd_wait_check)

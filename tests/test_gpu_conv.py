@@ -71,6 +71,11 @@ CASES = [
     ("dfirst_4to64", 4, 64, 4, 2, 2, 0, False, 0, False, 1, (3, 37, 50), False),
     ("dfirst_4to64_tiny", 4, 64, 4, 2, 2, 0, False, 0, False, 1, (1, 5, 3), False),
     ("dfirst_2to64_noact", 2, 64, 4, 2, 2, 0, False, 0, False, 0, (2, 16, 24), False),
+    # round 5: the discriminator's head (C -> 1, 4 x 4 stride 1, no norm, no activation): 16-bit types take csrc/dlast.hip for the
+    # forward and the input gradient (16 taps as an MFMA dimension), fp32 the W-fold path
+    ("dlast_512to1", 512, 1, 4, 1, 2, 0, False, 0, False, 0, (3, 21, 13), False),
+    ("dlast_128to1_tiny", 128, 1, 4, 1, 2, 0, False, 0, False, 0, (2, 3, 5), False),
+    ("dlast_384to1", 384, 1, 4, 1, 2, 0, False, 0, False, 0, (1, 40, 36), False),
 ]
 
 
@@ -417,7 +422,7 @@ def test_trunk_layer_at_baseline_size():
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 6e-3)], ids=["f32", "bf16"])
-@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide", "head_to1", "march_conv_transpose", "march_s2_conv"])
+@pytest.mark.parametrize("consumer", ["s2_conv", "s1_conv", "conv_transpose", "s1_256wide", "head_to1", "march_conv_transpose", "march_s2_conv", "dlast_head"])
 def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, tol, monkeypatch):
     """p2phd_conv_dgrad_bsum: the input-gradient kernel of the consumer leaves the (sum g', sum g' yhat) of the producer's
     InstanceNorm backward, which then runs its apply pass only.  Same gradients as the two-pass form (P2PHD_BSUM=0) up to
@@ -431,15 +436,18 @@ def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, 
         C1, H, W = 96, 16, 64
     if consumer == "march_s2_conv":                                # bf16: ... and here its transposed form
         C1, H, W = 48, 16, 128
+    if consumer == "dlast_head":                                   # round 5, bf16: the discriminator's 4 x 4 head on csrc/dlast.hip (fp32: W-fold path); odd plane
+        C1, H, W = 256, 33, 17
     c2 = {"march_conv_transpose": (C1, 48, 3, 2, 1, 0, True, 1), "march_s2_conv": (C1, 96, 3, 2, 1, 0, False, 0), "s2_conv": (C1, 32, 3, 2, 1, 0, False, 0), "s1_conv": (C1, 40, 3, 1, 1, 0, False, 0),
           "conv_transpose": (C1, 16, 3, 2, 1, 0, True, 1), "s1_256wide": (C1, 256, 3, 1, 1, 0, False, 0),
-          "head_to1": (C1, 1, 3, 1, 1, 0, False, 0)}[consumer]      # 1-channel head: output W-fold in front of the launch
+          "head_to1": (C1, 1, 3, 1, 1, 0, False, 0), "dlast_head": (C1, 1, 4, 1, 2, 0, False, 0)}[consumer]      # 1-channel head: output W-fold in front of the launch
     g = torch.Generator().manual_seed(11)
     x = torch.randn(N, C0, H, W, generator=g)
     w1 = torch.randn(C1, C0, 3, 3, generator=g) * 0.1
-    w2 = torch.randn((c2[0], c2[1], 3, 3) if c2[6] else (c2[1], c2[0], 3, 3), generator=g) * 0.05
+    w2 = torch.randn((c2[0], c2[1], c2[2], c2[2]) if c2[6] else (c2[1], c2[0], c2[2], c2[2]), generator=g) * 0.05
     specP = _ops.ConvSpec(C0, C1, 3, 1, 1, 0, False, 0, True, _ops.ACT_RELU)
-    specL = _ops.ConvSpec(*c2, consumer != "head_to1", _ops.ACT_RELU if consumer != "head_to1" else _ops.ACT_NONE)
+    head = consumer in ("head_to1", "dlast_head")
+    specL = _ops.ConvSpec(*c2, not head, _ops.ACT_RELU if not head else _ops.ACT_NONE)
 
     def run(flag):
         monkeypatch.setenv("P2PHD_BSUM", flag)
@@ -466,8 +474,8 @@ def test_instnorm_backward_sums_fused_into_the_consumers_dgrad(consumer, dtype, 
         if c2[6]:
             orr = F.conv_transpose2d(hr, w2r, stride=2, padding=1, output_padding=1)
         else:
-            orr = F.conv2d(hr, w2r, stride=c2[3], padding=1)
-        if consumer != "head_to1":
+            orr = F.conv2d(hr, w2r, stride=c2[3], padding=c2[4])
+        if not head:
             orr = F.relu(F.instance_norm(orr, eps=1e-5))
         orr.backward(torch.randn(orr.shape, generator=torch.Generator().manual_seed(5)))
         assert rel_err(o1.numpy(), orr.detach().numpy()) < 1e-4
@@ -951,3 +959,60 @@ def test_dfirst_kernel_equals_the_generic_path(dtype):
         assert rel_err(res[1], res[0]) < ulp, rel_err(res[1], res[0])
         assert rel_err(res[1], ref) < 2 * ulp and rel_err(res[0], ref) < 2 * ulp, (rel_err(res[1], ref), rel_err(res[0], ref))
         assert np.abs(res[1] - ref).max() <= 4 * ulp * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_dlast_kernels_equal_the_wfold_path(dtype):
+    """Round 5: csrc/dlast.hip (option dlast = 1) against the W-fold gather-GEMM launches it replaces (0) on the discriminator's
+    head at its real second-scale plane (512 channels, 33 x 17 -> 34 x 18) and an odd one: forward with bias, input gradient with
+    an addend, and the input gradient carrying the producer's InstanceNorm-backward sums (p2phd_conv_dgrad_bsum): outputs equal
+    to the 16-bit rounding (other summation order over the 8192 products), the fp32 sums to accumulation noise."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _ops.lib_for(dtype)
+    for (N, H, W, CH) in ((6, 33, 17, 512), (2, 9, 23, 256)):
+        gen = torch.Generator().manual_seed(H + CH)
+        spec = _ops.ConvSpec(CH, 1, 4, 1, 2, 0, False, 0, False, _ops.ACT_NONE)
+        d = spec.desc(N, H, W, dtype)
+        Ho, Wo = spec.out_size(d)
+        x = torch.randn(N, H, W, CH, generator=gen).cuda().to(dtype)
+        w = (torch.randn(1, CH, 4, 4, generator=gen) * 0.05).cuda()
+        b = (torch.randn(1, generator=gen)).cuda()
+        dy = torch.zeros(N, Ho, Wo, 8, device="cuda", dtype=dtype)
+        dy[..., 0] = torch.randn(N, Ho, Wo, generator=gen).cuda().to(dtype)
+        addend = torch.randn(N, H, W, CH, generator=gen).cuda().to(dtype)
+        prev_y = torch.randn(N, H, W, CH, generator=gen).cuda().to(dtype)
+        prev_stats = torch.zeros(N, CH, 2, device="cuda"); prev_stats[..., 0] = 0.1; prev_stats[..., 1] = H * W * 1.3
+        y = torch.empty(N, Ho, Wo, 8, device="cuda", dtype=dtype)
+        gx = torch.empty_like(x); gx2 = torch.empty_like(x)
+        bst = torch.zeros(N, CH, 2, device="cuda")
+        wp0, wp1 = spec.packed(w, 0, d), spec.packed(w, 1, d)
+        ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), L.p2phd_conv_dgrad_workspace_bytes(C.byref(d)),
+                                L.p2phd_conv_dgrad_bsum_workspace_bytes(C.byref(d)), 1 << 20), "cuda")
+        res = {}
+        try:
+            for opt in (0, 1):
+                _lib.check(L.p2phd_set_option(b"dlast", opt))
+                y.fill_(3.0); gx.fill_(3.0); gx2.fill_(3.0)
+                _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp0), _ops.ptr(b), 0, _ops.ptr(y), None, _ops.ptr(ws), _ops.stream_ptr()))
+                _ops.check(L.p2phd_conv_dgrad(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), _ops.ptr(addend), _ops.ptr(gx), _ops.ptr(ws), _ops.stream_ptr()))
+                _ops.check(L.p2phd_conv_dgrad_bsum(C.byref(d), _ops.ptr(dy), _ops.ptr(wp1), None, _ops.ptr(gx2), _ops.ptr(prev_y), _ops.ptr(prev_stats),
+                                                   _ops.ACT_LRELU, 1e-5, _ops.ptr(bst), _ops.ptr(ws), _ops.stream_ptr()))
+                torch.cuda.synchronize()
+                res[opt] = (y.float().cpu().numpy().copy(), gx.float().cpu().numpy().copy(), gx2.float().cpu().numpy().copy(), bst.cpu().numpy().copy())
+        finally:
+            _lib.check(L.p2phd_set_option(b"dlast", 1))
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        assert np.abs(res[1][0][..., 1:]).max() == 0.0                   # pad channels of the 1-channel output stay zero
+        for i, what in ((0, "y"), (1, "dx + addend"), (2, "dx (fused sums)")):
+            assert rel_err(res[1][i], res[0][i]) < ulp, (what, rel_err(res[1][i], res[0][i]))
+            assert np.abs(res[1][i] - res[0][i]).max() <= 2 * ulp * np.abs(res[0][i]).max(), what
+        assert rel_err(res[1][3], res[0][3]) < 2e-2 * (1 if dtype == torch.bfloat16 else 0.2), rel_err(res[1][3], res[0][3])   # sums of ROUNDED gradients that differ in the last bit
+        # against the fp32 oracle on the rounded operands
+        q = lambda t: t.float().cpu()
+        xr = q(x).permute(0, 3, 1, 2)
+        wq = w.cpu().to(dtype).float()
+        yo = F.conv2d(xr, wq, b.cpu(), padding=2)
+        assert rel_err(res[1][0][..., 0], yo[:, 0].numpy()) < 2 * ulp
+        gxo = F.conv_transpose2d(q(dy)[..., 0].unsqueeze(1), wq, padding=2).permute(0, 2, 3, 1)
+        assert rel_err(res[1][2], gxo.numpy()) < 2 * ulp
