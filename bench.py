@@ -483,7 +483,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process; the figure comes
         # from the separate rocprofv3 --pmc passes recorded in profiles/ (same kernel, same shapes, per launch)
         traffic, traffic_source = None, None
-        for name in ("r04_trunk_pmc.json", "r03_trunk_pmc.json", "r02_trunk_pmc.json", "r01_trunk_pmc.json"):
+        for name in ("r05_trunk_pmc.json", "r04_trunk_pmc.json", "r03_trunk_pmc.json", "r02_trunk_pmc.json", "r01_trunk_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     rec = json.load(f)

@@ -4,7 +4,7 @@
 # tools/summarize_profile.py turns the CSVs into the tracked files under profiles/.
 # The program after `--` is always python3 itself (no env / bash -c hop: the profiler has initialised the GPU by then).
 set -euo pipefail
-TAG="${1:-r04}"
+TAG="${1:-r05}"
 WHAT="${2:-all}"
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}"

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Memory-side traffic of one whole (eager) step (2 step-equivalents per pass: 1 warm-up + 1 timed, no probe steps): two separate --pmc passes, fresh output directories (see collect_profiles.sh).
 set -euo pipefail
-TAG="${1:-r04}"
+TAG="${1:-r05}"
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set: run this through gpurun}"
 OUT="gpurun_out/${TAG}t"

@@ -42,7 +42,10 @@ LABELS = (("gconv_kernelIDF16bLi256ELi192ELi2ELi3ELi2ELi1", "gconv_kernel<bf16,2
           ("gconv_kernelIDF16bLi256ELi256ELi4ELi2ELi2ELi0", "gconv_kernel<bf16,256,256,4,2,2> discriminator Conv4x4 256->512 @65x33 B=32 forward"),
           ("wgrad_kernelIDF16bLi256", "wgrad_kernel<bf16,256> trunk weight gradient 768x6912, 16384 pixels"),
           ("march_s_kernel<48, 96, 64, false, false>", "march_s_kernel<48,96,64> Conv3x3 s2 48->96 @512x256 B=32 forward (marching, round 4)"),
-          ("march_u_kernel<96, 48, 64, false, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"))
+          ("march_u_kernel<96, 48, 64, false, false>", "march_u_kernel<96,48,64> ConvTranspose3x3 s2 96->48 @256x128 B=32 forward (marching, round 4)"),
+          ("dfirst_fwd_kernel", "dfirst_fwd_kernel<4> discriminator first layer Conv4x4 s2 4->64 @512x256 2B=64 forward + LeakyReLU (round 5; algorithmic 134 + 272 MB)"),
+          ("dlast_fwd_partial_kernel", "dlast_fwd_partial_kernel<16> discriminator head Conv4x4 512->1 @66x34 2B=64 forward, pass 1 (round 5; algorithmic 147 MB read)"),
+          ("dlast_dgrad_kernel", "dlast_dgrad_kernel discriminator head input gradient @66x34 2B=64 with addend and fused InstanceNorm-backward sums (round 5; algorithmic 147 MB written + 2 x 147 MB read)"))
 
 
 def derive(paths, out, trunk_out):
@@ -119,7 +122,7 @@ def traffic(fetch_csv, write_csv, steps, out):
                 f"--warmup 1 --no-graph --no-probes --no-cpu-baseline --no-mdct` ({steps} step-equivalents per pass); FETCH_SIZE x2 (gfx950 counts 64 B per "
                 "128-B request), WRITE_SIZE as is; Infinity-Cache hits included (upper bounds on HBM traffic); times are those of the "
                 "instrumented FETCH pass.\n\n"
-                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22; round 2: 76.5 + 19.8; round 3: 73.5 + 19.7).\n\n"
+                f"**Whole step: {tot_r:.1f} GB read + {tot_w:.1f} GB written** (round 1: 86 + 22; round 2: 76.5 + 19.8; round 3: 73.5 + 19.7; round 4: 49.1 + 17.6).\n\n"
                 "| kernel | launches/step | read GB/step | written GB/step | time ms/step |\n|---|---|---|---|---|\n")
         for k, v in rows[:40]:
             f.write(f"| `{k[-70:]}` | {v[0] / steps:.1f} | {2 * v[1] * 1024 / steps / 1e9:.2f} | {v[2] * 1024 / steps / 1e9:.2f} | {v[3] / steps / 1e6:.2f} |\n")
@@ -167,8 +170,9 @@ def one_step(path, out):
     print("wrote", out, f"{b - a} launches {tot / 1e3:.2f} ms")
 
 
-ROUND_TAG = "r04"
-ROUND = "round 4"
+import os
+ROUND_TAG = os.environ.get("ROUND_TAG", "r05")
+ROUND = "round " + str(int(ROUND_TAG[1:]))
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
