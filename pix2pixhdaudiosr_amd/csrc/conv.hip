@@ -316,9 +316,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   P2PHD_CW_DECL;
   auto issue_piece = [&](int slot, int tile, int j) {
     char* A = stages + slot * STAGE + (8 * wave) * kRowBytes;
-#ifdef P2PHD_ABL_ADMA1
-    if (j >= 1 && j < NA) return;                              // experiment: one A piece per thread and slab (what an LDS halo would issue)
-#endif
     P2PHD_CW_ISSUE(slot);                                      // (check build: tag = the ring slot the piece fills)
     if (j < NA) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(A + RS * j * kRowBytes), 16, (int)va[j], 0, 0, 0);
@@ -364,17 +361,10 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
   uint4 af[NFB][MR], bfr[NFB][NR];
   auto read_frags = [&](unsigned so_, int ks, int buf) {
     const unsigned so = so_ + frag_base;
-#ifdef P2PHD_ABL_NOLDSREAD
-#pragma unroll
-    for (int i = 0; i < MR; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(af[buf][i].x) : "v"((fa[i] ^ (unsigned)(ks << 5)) + so));
-#pragma unroll
-    for (int j = 0; j < NR; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bfr[buf][j].x) : "v"((fb[j] ^ (unsigned)(ks << 5)) + so));
-#else
 #pragma unroll
     for (int i = 0; i < MR; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(af[buf][i]) : "v"((fa[i] ^ (unsigned)(ks << 5)) + so));
 #pragma unroll
     for (int j = 0; j < NR; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bfr[buf][j]) : "v"((fb[j] ^ (unsigned)(ks << 5)) + so));
-#endif
   };
   // One MFMA cluster (MR x NR tiles, one k-step); `h0` / `h1` are issued in the shadow of its first / second MFMA
   // (fragment reads, LDS-DMA issue), so the matrix pipe already has work when the wave turns to them.
@@ -383,12 +373,8 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       // (block-scaled form: see mfma8 below)
       (void)buf; (void)i; (void)j;
     } else if constexpr (sizeof(T) == 2) {
-#ifdef P2PHD_ABL_NOMFMA
-      asm volatile("" :: "v"(af[buf][i].x), "v"(af[buf][i].w), "v"(bfr[buf][j].x), "v"(bfr[buf][j].w));
-#else
       acc[i][j] = p2phd_mfma_32x32x16(*reinterpret_cast<bf16x8*>(&af[buf][i]),
                                                           *reinterpret_cast<bf16x8*>(&bfr[buf][j]), acc[i][j]);
-#endif
     } else {
       // exact f32 MFMA; any k permutation is fine as long as A and B share it
       const f32x4 a4 = *reinterpret_cast<f32x4*>(&af[buf][i]);
@@ -502,7 +488,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kScaled) mfma8(ks, 1); else if constexpr (MR * NR > 1) mfma_one(buf, 1 / NR, 1 % NR);
       __builtin_amdgcn_sched_barrier(0);
-#ifndef P2PHD_ABL_NODMA
       if (ks == 0 && pend) {
 #pragma unroll
         for (int j = 1; j < NLOADS; j += 2) issue_piece(pend_slot, pend_tile, j);
@@ -514,7 +499,6 @@ __global__ __launch_bounds__((BM / (MR * 32)) * (BN / (NR * 32)) * 64) void gcon
         for (int j = 0; j < NLOADS; j += 2) issue_piece(cur, s_begin + s + NSTAGE, j);
         pend = true; pend_slot = cur; pend_tile = s_begin + s + NSTAGE;
       }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (kScaled) {
 #pragma unroll
@@ -1018,13 +1002,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     const unsigned pix = (unsigned)(__mul24(pn, Hin) + hi) * (unsigned)Win + (unsigned)wi;
     return ok ? pix * CpiB : kOOB;
   };
-#ifdef P2PHD_ABL_WGRAD_NOPREP
-  int abl_prep = 0;
-#endif
   auto prepare = [&]() {
-#ifdef P2PHD_ABL_WGRAD_NOPREP
-    if (abl_prep++ >= 3) return;                                 // timing experiment only: stale gather offsets afterwards
-#endif
     if (pcur < P) {
       if (same_tap) {
         const unsigned o = pix_off(g_dh[0], g_dw[0]);
@@ -1065,12 +1043,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
   P2PHD_CW_DECL;
   auto issue_piece = [&](int slot_, int j) {
     char* A = smem + slot_ * STAGE;
-#ifdef P2PHD_ABL_WGRAD_GDMA1
-    if (j >= 1 && j < PPT) return;                               // experiment: one gather piece per thread and step
-#endif
-#ifdef P2PHD_ABL_WGRAD_ADMA1
-    if (j >= PPT + 1) return;                                    // experiment: one rows-operand piece per thread and step
-#endif
     P2PHD_CW_ISSUE(slot_);
     if (j < PPT) {
       char* G = A + TILEA + (grp * PPT + j) * PANEL + wrow8 * 128;
@@ -1125,24 +1097,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
     P2PHD_TR_READ(hi, addr, 16 * (SUB) * (PITCH) + 4 * (PITCH));                                       \
   } while (0)
     auto read_frags = [&](unsigned so, int sub, int buf) {
-#if defined(P2PHD_ABL_WGRAD_B128A) || defined(P2PHD_ABL_WGRAD_B128AG)
-      // experiment (timing only, wrong numbers): the rows operand's fragments as ONE ds_read_b128 each instead of two transposing reads
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        uint4 v4;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v4) : "v"((so + ta_off[i] + (unsigned)(sub * 2048)) & ~15u));
-        af[buf][i][0] = make_uint2(v4.x, v4.y); af[buf][i][1] = make_uint2(v4.z, v4.w);
-      }
-#ifdef P2PHD_ABL_WGRAD_B128AG
-#pragma unroll
-      for (int j = 0; j < NI; ++j) {
-        uint4 v4;
-        asm volatile("ds_read_b128 %0, %1" : "=v"(v4) : "v"((so + tg_off[j] + (unsigned)(sub * 2048)) & ~15u));
-        gf[buf][j][0] = make_uint2(v4.x, v4.y); gf[buf][j][1] = make_uint2(v4.z, v4.w);
-      }
-      return;
-#endif
-#else
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
         const unsigned ad = so + ta_off[i];
@@ -1153,7 +1107,6 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
           default: P2PHD_TR_PAIR(af[buf][i][0], af[buf][i][1], ad, 3, RPA); break;
         }
       }
-#endif
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
         const unsigned ad = so + tg_off[j];
@@ -1326,14 +1279,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const GDesc d, const T* __re
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row_o = m0 + wm * (MI * 32) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-#ifdef P2PHD_ABL_WGRAD_NOSTORE
-        if (acc[i][j][e] == 123456.f)                              // experiment: no slab stores (timing only)
-#endif
-#ifdef P2PHD_ABL_WGRAD_NTSTORE
-        __builtin_nontemporal_store(acc[i][j][e], &slab[(size_t)row_o * KK + col]);
-#else
         slab[(size_t)row_o * KK + col] = acc[i][j][e];
-#endif
       }
     }
 }
