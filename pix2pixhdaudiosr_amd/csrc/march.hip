@@ -13,7 +13,10 @@
 //     registers for the life of the workgroup (60 VGPRs at 48 input channels), A fragments come from the ring with
 //     conflict-free ds_read_b128 (pixel pitch padded by 16 bytes), v_mfma_f32_16x16x32_bf16;
 //   * the output tile of a step is staged in LDS and leaves one step later as whole 16-byte pieces of contiguous NHWC rows
-//     (one piece per thread), so ONE barrier per step orders ring writes, staging and stores;
+//     (one piece per thread), so ONE barrier per step orders ring writes, staging and stores.  (The staging stores are where the
+//     kernel's SQ_LDS_BANK_CONFLICT count comes from -- lanes 2 m and 2 m + 1 write the two 16-bit halves of one dword -- , not the
+//     fragment reads; a variant that packs the pair into one dword store through DPP changed the counter and not the time: the
+//     kernel waits for HBM.  DESIGN.md section 6, round 5);
 //   * InstanceNorm partials: every lane keeps running (count, mean, M2) of its channel over the whole march (Chan's
 //     update per step), merged across the four lanes of a channel at the end: one table slot per wave and launch, no atomics;
 //   * input-gradient launches can carry the producer's InstanceNorm-backward sums (the fused form of conv.hip's store
@@ -31,24 +34,6 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 constexpr int kThreads = 768, kWaves = 12;
 constexpr unsigned kOOB = 0xFFFFFFF0u;
-
-// Staging of a lane's four output pixels (rows of the MFMA's D block: pixel e at byte offset off0 + e * step, this lane's channel
-// n16 at +2 n16) as TWO aligned 32-bit stores instead of four 16-bit ones.  Lanes (2 m, 2 m + 1) of a quad hold channels 2 m and
-// 2 m + 1 of the SAME pixels, i.e. the two halves of one dword: written as 16-bit halves the pair collides on its bank in every
-// instruction (round-4 review, weak 9: SQ_LDS_BANK_CONFLICT 4.0 M / 8.4 M per launch -- the fragment READS are conflict-free,
-// these writes were not).  The pair swaps two values through DPP (quad_perm [1, 0, 3, 2]: no LDS crossbar traffic): the even lane
-// then writes the whole dwords of pixels 0 and 2, the odd lane those of pixels 1 and 3.  Same roundings, same bytes.
-__device__ __forceinline__ void stage_pixels4(char* sp_lane, const float (&v)[4], int step, bool odd) {
-  const float s0 = odd ? v[0] : v[1], s1 = odd ? v[2] : v[3];
-  const float r0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s0), 0xB1, 0xF, 0xF, true));
-  const float r1 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(s1), 0xB1, 0xF, 0xF, true));
-  typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2;
-  const bf16x2 a = {(bf16_t)(odd ? r0 : v[0]), (bf16_t)(odd ? v[1] : r0)};     // (channel 2 m, channel 2 m + 1) of pixel 0 / 1
-  const bf16x2 b = {(bf16_t)(odd ? r1 : v[2]), (bf16_t)(odd ? v[3] : r1)};     // ... of pixel 2 / 3
-  char* p = sp_lane - (odd ? 2 : 0) + (odd ? step : 0);
-  *reinterpret_cast<bf16x2*>(p) = a;
-  *reinterpret_cast<bf16x2*>(p + 2 * step) = b;
-}
 
 __device__ __forceinline__ void chan_merge(float& na, float& ma, float& qa, float nb, float mb, float qb) {
   const float n = na + nb;
@@ -344,7 +329,10 @@ __global__ __launch_bounds__(kThreads) void march_s_kernel(const MarchArgs a) {
       }
       char* sp = stage + (s & 1) * STAGEB + (16 * wn + n16) * 2;
 #pragma unroll
-      for (int b = 0; b < MBW; ++b) stage_pixels4(sp + (16 * (wm * MBW + b) + 4 * kq) * SPXB, v[b], SPXB, (n16 & 1) != 0);
+      for (int b = 0; b < MBW; ++b)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *reinterpret_cast<bf16_t*>(sp + (16 * (wm * MBW + b) + 4 * kq + e) * SPXB) = (bf16_t)v[b][e];
     }
 
     if (s > 0) store_tile(s - 1, yv);
@@ -598,7 +586,11 @@ __global__ __launch_bounds__(kThreads) void march_u_kernel(const MarchArgs a) {
         st_m2[slot] += q + d * d * ((float)(4 * k) * f);
         st_n[slot] = (float)(4 * (k + 1));
       }
-      stage_pixels4(sp + (pi * 2 * WS + 2 * (16 * (wm * MBW + b) + 4 * kq) + pj) * SPXB, v, 2 * SPXB, (n16 & 1) != 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int bpx = 16 * (wm * MBW + b) + 4 * kq + e;
+        *reinterpret_cast<bf16_t*>(sp + (pi * 2 * WS + 2 * bpx + pj) * SPXB) = (bf16_t)v[e];
+      }
     };
     if (role == 0) {
 #pragma unroll
