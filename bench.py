@@ -217,7 +217,12 @@ def cpu_baseline(sample_batch=2, steps=3):
     torch.set_num_threads(host_cores())
     v1, dt1 = _cpu_leg(48, sample_batch, steps)
     v0, dt0 = _cpu_leg(32, sample_batch, steps)
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
     return {"value": v1, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port", "cpu": cpu_model_name(),
+            "cores_visible": visible, "cores_note": "threads used = min(visible cores, 16): a one-GPU box's CPU share is 16 cores",
             "sample": f"oracle full_step (CPU port of train.py:148-184), configs[1]'s network/config at batch {sample_batch}, "
                       f"1 warm-up + {steps} timed step(s), fp32, {dt1:.2f} s/step",
             "configs0": {"value": v0, "unit": "frames/s",
