@@ -1016,3 +1016,64 @@ def test_dlast_kernels_equal_the_wfold_path(dtype):
         assert rel_err(res[1][0][..., 0], yo[:, 0].numpy()) < 2 * ulp
         gxo = F.conv_transpose2d(q(dy)[..., 0].unsqueeze(1), wq, padding=2).permute(0, 2, 3, 1)
         assert rel_err(res[1][2], gxo.numpy()) < 2 * ulp
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dfirst_and_dlast_on_random_planes(seed):
+    """Round 5: csrc/dfirst.hip / csrc/dlast.hip on planes of random size (odd, tiny, non-multiples of the 16-pixel block; batches that do
+    not fill a wave's run of blocks) against torch's fp32 convolution of the bf16-rounded operands: forward of both, input gradient
+    of the head with and without an addend.  The kernels index a FLATTENED pixel axis (dfirst, dlast forward) or per-sample runs of
+    16-pixel blocks (dlast input gradient): every boundary between rows, samples and the padded tail is hit somewhere here."""
+    from pix2pixhdaudiosr_amd import _ops
+    import ctypes as C
+    dtype = torch.bfloat16
+    L = _ops.lib_for(dtype)
+    rng = np.random.RandomState(100 + seed)
+    q = lambda t: t.to(dtype).float()
+    ulp = 2.0 ** -8
+    for _ in range(6):
+        N, H, W = int(rng.randint(1, 5)), int(rng.randint(2, 40)), int(rng.randint(2, 40))
+        gen = torch.Generator().manual_seed(int(rng.randint(1 << 30)))
+        # first layer: C in {1..4} -> 64, 4 x 4 stride 2 pad 2, LeakyReLU
+        cin = int(rng.randint(1, 5))
+        spec = _ops.ConvSpec(cin, 64, 4, 2, 2, 0, False, 0, False, _ops.ACT_LRELU)
+        d = spec.desc(N, H, W, dtype)
+        Ho, Wo = spec.out_size(d)
+        xc = torch.randn(N, cin, H, W, generator=gen)
+        w = torch.randn(64, cin, 4, 4, generator=gen) * 0.1
+        b = torch.randn(64, generator=gen) * 0.1
+        x = _ops.ToPhysical.apply(dtype, xc.cuda())
+        y = torch.full((N, Ho, Wo, 64), 9.0, device="cuda", dtype=dtype)
+        ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 1 << 16), "cuda")
+        _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(spec.packed(w.cuda(), 0, d)), _ops.ptr(b.cuda()), _ops.ACT_LRELU, _ops.ptr(y), None,
+                                    _ops.ptr(ws), _ops.stream_ptr()))
+        ref = F.leaky_relu(F.conv2d(q(xc), q(w), b, stride=2, padding=2), 0.2).permute(0, 2, 3, 1).numpy()
+        assert rel_err(y.float().cpu().numpy(), ref) < 2 * ulp, ("dfirst", N, H, W, cin)
+        # head: C in {128, 256, 384, 512} -> 1, 4 x 4 stride 1 pad 2
+        ch = int(rng.choice([128, 256, 384, 512]))
+        spec = _ops.ConvSpec(ch, 1, 4, 1, 2, 0, False, 0, False, _ops.ACT_NONE)
+        d = spec.desc(N, H, W, dtype)
+        Ho, Wo = spec.out_size(d)
+        xh = torch.randn(N, H, W, ch, generator=gen).cuda().to(dtype)
+        wh = torch.randn(1, ch, 4, 4, generator=gen) * 0.05
+        bh = torch.randn(1, generator=gen)
+        yh = torch.full((N, Ho, Wo, 8), 9.0, device="cuda", dtype=dtype)
+        ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), L.p2phd_conv_dgrad_workspace_bytes(C.byref(d)), 1 << 16), "cuda")
+        _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(xh), _ops.ptr(spec.packed(wh.cuda(), 0, d)), _ops.ptr(bh.cuda()), 0, _ops.ptr(yh), None, _ops.ptr(ws),
+                                    _ops.stream_ptr()))
+        refh = F.conv2d(xh.float().cpu().permute(0, 3, 1, 2), q(wh), bh, padding=2)[:, 0].numpy()
+        got = yh.float().cpu().numpy()
+        assert np.abs(got[..., 1:]).max() == 0.0
+        assert rel_err(got[..., 0], refh) < 2 * ulp, ("dlast fwd", N, H, W, ch)
+        dy = torch.zeros(N, Ho, Wo, 8, device="cuda", dtype=dtype)
+        dyc = torch.randn(N, Ho, Wo, generator=gen)
+        dy[..., 0] = dyc.cuda().to(dtype)
+        addend = torch.randn(N, H, W, ch, generator=gen).cuda().to(dtype)
+        for add in (None, addend):
+            gx = torch.full((N, H, W, ch), 9.0, device="cuda", dtype=dtype)
+            _ops.check(L.p2phd_conv_dgrad(C.byref(d), _ops.ptr(dy), _ops.ptr(spec.packed(wh.cuda(), 1, d)), _ops.ptr(add), _ops.ptr(gx), _ops.ptr(ws),
+                                          _ops.stream_ptr()))
+            refg = q(F.conv_transpose2d(q(dyc).unsqueeze(1), q(wh), padding=2).permute(0, 2, 3, 1))
+            if add is not None:
+                refg = refg + add.float().cpu()
+            assert rel_err(gx.float().cpu().numpy(), refg.numpy()) < 2 * ulp, ("dlast dgrad", N, H, W, ch, add is not None)
