@@ -69,7 +69,7 @@ int p2phd_probe_gconv_ex(int enable, int cin_pitch, int kk, int hg, int wg, int 
 int p2phd_probe_read(float* ms_out, int cap);
 /* Launch counters: how many launches of a kernel family the library has made since the last reset -- "gconv" (every
  * gather-GEMM launch), "halo" (those on the patch-staged 3x3 main loop), "cls_skip" (tap-skipping merged stride-2 launches),
- * "splitk" (launches with a split-K tail), "tile256" (256 x 256 tiles), "patch" (the patch-staged 4x4 discriminator loop),
+ * "splitk" (launches with a split-K tail), "tile256" (256 x 256 tiles), "tile128x192" (128 x 192 tiles of small planes),
  * "march" / "march_w" (marching kernels), "wgrad" (MFMA weight gradient).  family == NULL with reset != 0 clears all.
  * Returns the count before the reset, -1 for an unknown name.  Counts launches recorded under graph capture once (at capture).
  * Test hook: proves which kernels a whole training step really runs on (train.py:148-184 at the benchmarked batch). */

@@ -1935,6 +1935,7 @@ int launch_gconv_cfg(const GDesc& d_in, const void* in, const void* wp, const fl
   if (d.cls_skip != 0) ++p2phd::g_launch_count[p2phd::LC_CLS_SKIP];
   if (d.sk_parts > 1) ++p2phd::g_launch_count[p2phd::LC_SPLITK];
   if (BM == 256 && BN == 256) ++p2phd::g_launch_count[p2phd::LC_TILE256];
+  if (BM == 128 && BN == 192) ++p2phd::g_launch_count[p2phd::LC_TILE128X192];
   if (probe) { (void)hipEventRecord(e1, st); g_probe_cfg.ev.emplace_back(e0, e1); }
   return p2phd::check_launch("gconv");
 }
@@ -2022,6 +2023,15 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
   if (big && bn == 64) {
     if (fits3) return launch_gconv_cfg<T, 256, 64, 2, 1, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
     return launch_gconv_cfg<T, 256, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+  }
+  // 128 x 192 (4 waves of 64 x 96): planes too small for 256-row tiles whose 128 x 128 grid would run a second, half-empty
+  // round (the 1536-channel trunk of the two-scale generator at 16 x 8: 32 x 12 = 384 tiles -> 32 x 8 = 256)
+  if constexpr (sizeof(T) == 2) {
+    const long mt128 = (long)((npix + 127) / 128) * d.N;
+    const long wg128 = mt128 * ((k + 127) / 128), wg192 = mt128 * (k / 192);
+    if (force == 0 && !d.flat_m && !short_k && k % 192 == 0 && k >= 384 && p2phd::g_opt_tile128x192 != 0 &&
+        std::ceil(wg192 / 256.0) * 192.0 < std::ceil(wg128 / 512.0) * 2.0 * 128.0 && wg192 >= 192)
+      return launch_gconv_cfg<T, 128, 192, 2, 3, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   if (bn == 128) return launch_gconv_cfg<T, 128, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   if (bn == 64) return launch_gconv_cfg<T, 128, 64, 2, 1, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);

@@ -70,12 +70,13 @@ int launch_pack_fp8(const GDesc& d, const WMap& m, const float* w, void* wp8, in
 
 // launch counters (p2phd_launch_count): which kernel family a call really took -- tests assert that the benchmarked step runs
 // on the round-4/5 kernels and not on the generic loop behind them
-enum LaunchFamily { LC_GCONV = 0, LC_HALO, LC_CLS_SKIP, LC_MARCH, LC_MARCH_W, LC_WGRAD, LC_SPLITK, LC_TILE256, LC_PATCH, LC_FAMILIES };
+enum LaunchFamily { LC_GCONV = 0, LC_HALO, LC_CLS_SKIP, LC_MARCH, LC_MARCH_W, LC_WGRAD, LC_SPLITK, LC_TILE256, LC_TILE128X192, LC_FAMILIES };
 extern unsigned long long g_launch_count[LC_FAMILIES];
 
 // tuning overrides (p2phd_set_option): 0 = heuristic
 extern int g_opt_gconv_bm;
 extern int g_opt_wgrad_tm;
+extern int g_opt_tile128x192;      // 1 (default): small planes with 192-divisible outputs take the 128 x 192 tile where it saves a round
 extern int g_opt_wgrad_xcd;          // 1 (default): XCD-aware tile order of the weight-gradient grid, 0: plain order (A/B)
 extern int g_opt_c7_generic;
 extern int g_opt_splitk_tail;       // 0: every tile is one workgroup, 1 (default): split-K tail where the cost model says so, 2: wherever possible (tests)

@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...) {
 }
 }  // namespace p2phd
 
-namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_wgrad_xcd = 1; int g_opt_march = 1; int g_opt_cls_skip = 1; int g_opt_gconv_halo = 1; int g_opt_cw_inject = 0; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
+namespace p2phd { int g_opt_gconv_bm = 0; int g_opt_wgrad_tm = 0; int g_opt_wgrad_xcd = 1; int g_opt_march = 1; int g_opt_cls_skip = 1; int g_opt_gconv_halo = 1; int g_opt_cw_inject = 0; int g_opt_tile128x192 = 1; int g_opt_mdct_generic = 0; int g_opt_mdct_iters = 0; int g_opt_c7_generic = 0; int g_opt_c7_abl = 0; int g_opt_reflect_generic = 0; int g_opt_splitk_tail = 1; int g_opt_cus = 0;
 unsigned long long g_launch_count[LC_FAMILIES] = {};
 int device_cus() {
   static int cached[64] = {};
@@ -116,6 +116,7 @@ extern "C" int p2phd_set_option(const char* name, int value) {
   if (name && !strcmp(name, "march") && (value == 0 || value == 1)) { p2phd::g_opt_march = value; return P2PHD_OK; }
   if (name && !strcmp(name, "cls_skip") && (value == 0 || value == 1)) { p2phd::g_opt_cls_skip = value; return P2PHD_OK; }   // (changes the packed layout: repack after a change)
   if (name && !strcmp(name, "gconv_halo") && (value == 0 || value == 1)) { p2phd::g_opt_gconv_halo = value; return P2PHD_OK; }
+  if (name && !strcmp(name, "tile128x192") && (value == 0 || value == 1)) { p2phd::g_opt_tile128x192 = value; return P2PHD_OK; }   // (A/B: the 128 x 192 tile of small planes vs 128 x 128)
   if (name && !strcmp(name, "dlast") && (value == 0 || value == 1)) { p2phd::g_opt_dlast = value; return P2PHD_OK; }     // (A/B, parity tests: dlast.hip vs the W-fold path)
   if (name && !strcmp(name, "dfirst") && (value == 0 || value == 1)) { p2phd::g_opt_dfirst = value; return P2PHD_OK; }   // (A/B, parity tests: dfirst.hip vs the W-fold path)
 #ifdef P2PHD_CHECK_WAITS
@@ -134,7 +135,7 @@ extern "C" int p2phd_set_option(const char* name, int value) {
 }
 
 extern "C" int64_t p2phd_launch_count(const char* family, int reset) {
-  static const char* names[p2phd::LC_FAMILIES] = {"gconv", "halo", "cls_skip", "march", "march_w", "wgrad", "splitk", "tile256", "patch"};
+  static const char* names[p2phd::LC_FAMILIES] = {"gconv", "halo", "cls_skip", "march", "march_w", "wgrad", "splitk", "tile256", "tile128x192"};
   if (family == nullptr) {                                       // all families at once
     if (reset) for (auto& c : p2phd::g_launch_count) c = 0;
     return 0;

@@ -76,6 +76,11 @@ CASES = [
     ("dlast_512to1", 512, 1, 4, 1, 2, 0, False, 0, False, 0, (3, 21, 13), False),
     ("dlast_128to1_tiny", 128, 1, 4, 1, 2, 0, False, 0, False, 0, (2, 3, 5), False),
     ("dlast_384to1", 384, 1, 4, 1, 2, 0, False, 0, False, 0, (1, 40, 36), False),
+    # round 5: the 128 x 192 tile of planes too small for 256-row tiles (the 1536-channel trunk of the two-scale generator at
+    # 16 x 8, 16-bit types, >= 192 tiles): forward with InstanceNorm partial sums, and the input gradient through the reflection
+    # adjoint's extras
+    ("tile128x192_fwd_64to1152", 64, 1152, 3, 1, 1, 1, False, 0, True, 3, (32, 16, 8), False),
+    ("tile128x192_dgrad_1152to64", 1152, 64, 3, 1, 1, 1, False, 0, True, 3, (32, 16, 8), False),
 ]
 
 
@@ -1077,3 +1082,42 @@ def test_dfirst_and_dlast_on_random_planes(seed):
             if add is not None:
                 refg = refg + add.float().cpu()
             assert rel_err(gx.float().cpu().numpy(), refg.numpy()) < 2 * ulp, ("dlast dgrad", N, H, W, ch, add is not None)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_tile128x192_equals_the_128x128_tile(dtype):
+    """Round 5: the 128 x 192 tile (option tile128x192 = 1) that the 1536-channel trunk of the two-scale generator takes on its
+    16 x 8 plane (configs[2]/[3]) against the 128 x 128 tile (0): the K order of every output element is the same in both, so the
+    outputs and the InstanceNorm partial sums are equal BIT FOR BIT; the launch counter shows which tile ran."""
+    from pix2pixhdaudiosr_amd import _ops, _lib
+    import ctypes as C
+    L = _ops.lib_for(dtype)
+    N, H, W, cin, cout = 32, 16, 8, 192, 1536
+    gen = torch.Generator().manual_seed(5)
+    spec = _ops.ConvSpec(cin, cout, 3, 1, 1, 1, False, 0, True, _ops.ACT_RELU)
+    d = spec.desc(N, H, W, dtype)
+    x = torch.randn(N, H, W, cin, generator=gen).to(dtype).cuda()
+    w = (torch.randn(cout, cin, 3, 3, generator=gen) * 0.05).cuda()
+    y = torch.empty(N, H, W, cout, device="cuda", dtype=dtype)
+    stats = torch.zeros(N, cout, 2, device="cuda")
+    wp = spec.packed(w, 0, d)
+    ws = _ops.workspace(max(L.p2phd_conv_fwd_workspace_bytes(C.byref(d)), 1 << 20), "cuda")
+    res, cnt = {}, {}
+    try:
+        _lib.check(L.p2phd_set_option(b"splitk_tail", 0))        # (a split-K tail of the 128 x 128 grid would sum K in two parts)
+        for opt in (0, 1):
+            _lib.check(L.p2phd_set_option(b"tile128x192", opt))
+            L.p2phd_launch_count(None, 1)
+            y.fill_(7.0); stats.zero_()
+            _ops.check(L.p2phd_conv_fwd(C.byref(d), _ops.ptr(x), _ops.ptr(wp), None, 0, _ops.ptr(y), _ops.ptr(stats), _ops.ptr(ws), _ops.stream_ptr()))
+            torch.cuda.synchronize()
+            cnt[opt] = L.p2phd_launch_count(b"tile128x192", 0)
+            res[opt] = (y.clone(), stats.clone())
+    finally:
+        _lib.check(L.p2phd_set_option(b"tile128x192", 1))
+        _lib.check(L.p2phd_set_option(b"splitk_tail", 1))
+    assert cnt == {0: 0, 1: 1}, cnt
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    ref = F.conv2d(F.pad(x.float().permute(0, 3, 1, 2), (1, 1, 1, 1), mode="reflect"), w.to(dtype).float()).permute(0, 2, 3, 1)
+    assert rel_err(res[1][0].float().cpu().numpy(), ref.cpu().numpy()) < (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10)
