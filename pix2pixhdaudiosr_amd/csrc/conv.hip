@@ -2017,6 +2017,10 @@ int launch_gconv_t(GDesc d, const void* in, const void* wp, const float* bias, c
     if (huge) return launch_gconv_cfg<T, 256, 256, 4, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }
   if (big && bn == 128) {
+    if constexpr (sizeof(T) == 2) {                            // the HALO loop on 128-wide tiles: 16-wide planes whose 192- / 256-wide grids leave CUs idle
+      if (force == 0 && k % 128 == 0 && !short_k && gconv_halo_ok(d))   // (configs[4]'s 2048-channel trunk at B = 8; the 768-channel trunk below B = 27)
+        return launch_gconv_cfg<T, 256, 128, 2, 2, 2, 1>(d, in, wp, bias, addend, out, stats, st, slot_rows);
+    }
     if (fits3) return launch_gconv_cfg<T, 256, 128, 2, 2, 3>(d, in, wp, bias, addend, out, stats, st, slot_rows);
     return launch_gconv_cfg<T, 256, 128, 2, 2, 2>(d, in, wp, bias, addend, out, stats, st, slot_rows);
   }

@@ -589,12 +589,14 @@ def test_reflection_extras_written_by_the_instancenorm_backward(geom, dtype, tol
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("geom", [(32, 32, 768), (56, 16, 768), (10, 96, 768)], ids=["trunk_32x16x768", "16rows", "96rows_forward_only"])
+@pytest.mark.parametrize("geom", [(32, 32, 768), (56, 16, 768), (10, 96, 768), (16, 32, 768)],
+                         ids=["trunk_32x16x768", "16rows", "96rows_forward_only", "batch16_on_256x128_tiles"])
 def test_halo_loop_equals_the_generic_loop(geom, dtype):
     """Round 4: the HALO main loop of the 256 x 192 tile (csrc/gconv_halo.inc, option gconv_halo) against the generic loop
     on the same launches -- the residual-trunk layer at its real size, forward (ReflectionPad2d(1) gather) with statistics
     and input gradient through the reflection extras --, on a 16-row plane (one tile holds both borders) and, forward only, on a
-    96-row plane (tiles with no image border; planes above 640 pixels take the two-pass InstanceNorm backward, which has no extras).
+    96-row plane (tiles with no image border; planes above 640 pixels take the two-pass InstanceNorm backward, which has no extras);
+    at batch 16 the grid takes 256 x 128 tiles (round 5: the HALO loop's second instantiation -- configs[4]'s 2048-channel trunk at B = 8).
     The two loops add the same products in a different order (chunk-tap-channel against tap-channel): outputs agree to
     the rounding of the 16-bit store, the fp32 statistics to accumulation noise."""
     from pix2pixhdaudiosr_amd import _ops, _lib
