@@ -53,7 +53,18 @@ const char* p2phd_last_error(void);
 int p2phd_abi_version(void);
 /* fills name (<= cap bytes) with the device's gcnArchName; returns CU count or <0 */
 int p2phd_device_info(char* name, int cap);
-/* tuning overrides for tests and A/B timing: "gconv_bm" = 0 (heuristic) | 128 | 256 */
+/* Per-library options (process-wide; tests, A/B timing, and one that the data-parallel step sets).  Unknown name or value: P2PHD_EINVAL.
+ *   "cus" n            CUs a conv launch may count on when the step runs on a CU-masked stream (0 = all of the device's)
+ *   "gconv_bm" v       gather-GEMM tile: 0 heuristic | 128 | 192 | 256 | 258 (256 rows on the 2-slot ring) | 512 (256 x 256)
+ *   "gconv_halo" 0|1   the HALO main loop of 3x3 stride-1 layers on 16-wide planes (1) or the generic loop (0)
+ *   "tile128x192" 0|1  the 128 x 192 tile of small planes with 192-divisible outputs
+ *   "cls_skip" 0|1     tap-skipping merged stride-2 launches (changes the packed layout of those layers: see p2phd_conv_pack_layout)
+ *   "splitk_tail" 0|1|2  split-K of the last, partly filled tile round: off | where the cost model says so | wherever possible
+ *   "march", "dfirst", "dlast", "c7_generic", "reflect_generic", "mdct_generic" 0|1   the dedicated kernels of the outermost
+ *                      stride-2 pair, the discriminator's first / last layer, the two 7x7 layers, the reflection extras, the fast MDCT:
+ *                      on (default; c7_generic / reflect_generic / mdct_generic = 1 select the generic path instead)
+ *   "wgrad_tm" 0|128, "wgrad_xcd" 0|1, "mdct_iters" 0..8, "c7_abl"   weight-gradient row tile / XCD-aware order, experiment knobs
+ *   "cw_inject" 0|1    libp2phd_hip_chk.so only: selects round 4's too-lax HALO wait (sensitivity check of p2phd_wait_check) */
 int p2phd_set_option(const char* name, int value);
 /* zeroes the arrival tickets of the fixed-order reductions on `stream` (13 KB memset; see "Streams" above) */
 int p2phd_reduction_reset(void* stream);
